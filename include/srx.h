@@ -1,0 +1,215 @@
+/*
+ * srx.h -- C ABI of libsrx.so: the MI355X (gfx950) implementation of the acoustic hot path
+ * of albinoBandicoot/speechRecognition (MFCC extraction, diagonal-GMM emission scoring,
+ * Viterbi forced alignment, embedded-training statistics).
+ *
+ * The reference has no FFI/plugin layer: it is one C++ program.  The boundary replaced is
+ * the C++ surface its headless main() calls.  Each entry point below
+ * cites the reference function(s) it stands in for, paths relative to the reference tree.
+ * The C++ classes in speechrecognition_amd/host/ (same names as the reference's) are thin
+ * wrappers over this header; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every call returns SRX_OK (0) or a negative srx_status; srx_last_error() has the text;
+ *   - no C++ exception and no HIP/torch type crosses this boundary: plain pointers + sizes;
+ *   - names ending in _dev take DEVICE pointers and are asynchronous on the context's
+ *     stream; all other calls take HOST pointers and are synchronous on return;
+ *   - a context is used by one host thread at a time;
+ *   - there is no CPU fallback: without a gfx950 device srx_ctx_create fails.
+ */
+#ifndef SRX_H
+#define SRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SRX_OK = 0,
+    SRX_ERR_INVALID = -1,   /* bad argument (shape, null pointer, unsupported size) */
+    SRX_ERR_DEVICE = -2,    /* HIP runtime error */
+    SRX_ERR_NOMEM = -3,     /* device or host allocation failed */
+    SRX_ERR_IO = -4,        /* file could not be opened (reference: `throw 1`, src/mfcc.cpp:237,281) */
+    SRX_ERR_UNSUPPORTED = -5
+} srx_status;
+
+typedef struct srx_ctx srx_ctx;
+
+/* ---------------------------------------------------------------- context ---------- */
+/* One per GPU.  `stream` is a hipStream_t to launch on (NULL: the context creates its own). */
+int srx_ctx_create(int device, void *stream, srx_ctx **out);
+void srx_ctx_destroy(srx_ctx *ctx);
+const char *srx_last_error(const srx_ctx *ctx); /* ctx may be NULL: last creation error */
+int srx_sync(srx_ctx *ctx);
+const char *srx_version(void);
+
+/* Device-memory plumbing so that C/C++ callers need no HIP headers. */
+int srx_malloc(srx_ctx *ctx, size_t bytes, void **dev);
+int srx_free(srx_ctx *ctx, void *dev);
+int srx_memcpy_h2d(srx_ctx *ctx, void *dev, const void *host, size_t bytes);
+int srx_memcpy_d2h(srx_ctx *ctx, void *host, const void *dev, size_t bytes);
+int srx_memset(srx_ctx *ctx, void *dev, int value, size_t bytes);
+
+/* ---------------------------------------------------------------- filterbank -------- */
+/* filter {center,width,height}: src/mfcc.hpp:50-60 */
+typedef struct {
+    float center, width, height;
+} srx_filter;
+
+/* mel_filterbank(end, n, dft_bins, sps)  src/mfcc.cpp:190-201 (+ filter ctor :117-128,
+ * ofMap of OpenFrameworks).  Host-side constants; writes n filters and bin_max
+ * (src/mfcc.cpp:220-221). */
+int srx_mel_filterbank(float end, int n, int dft_bins, int sps, srx_filter *out, int *bin_max);
+
+/* ---------------------------------------------------------------- MFCC -------------- */
+typedef struct {
+    int window_len;     /* 320 in src/main.cpp:83 (400 for 25 ms) */
+    int frame_shift;    /* 160 */
+    int n_ceps;         /* NPARAMS = 13, src/mfcc.hpp:17 */
+    int normalize;      /* 1: apply Clip::normalizeVolume(target_rms) first (src/main.cpp:79) */
+    float target_rms;   /* 1.0f */
+    int preemphasis;    /* 1: apply Clip::preemphasis(alpha) (src/mfcc.cpp:238) */
+    float alpha;        /* 0.96f */
+} srx_mfcc_cfg;
+
+typedef struct srx_mfcc_plan srx_mfcc_plan;
+
+/* Builds the device tables (window, twiddles, filterbank matrix, DCT matrix) for a
+ * configuration + filterbank.  Replaces the per-frame recomputation in
+ * hamming_window (src/utils.cpp:21-23), Clip::partial_dft (src/clip.cpp:174-194),
+ * filter::get (src/mfcc.cpp:132-140) and dct (src/mfcc.cpp:205-214). */
+int srx_mfcc_plan_create(srx_ctx *ctx, const srx_mfcc_cfg *cfg, const srx_filter *fb, int n_filters,
+                         srx_mfcc_plan **out);
+void srx_mfcc_plan_destroy(srx_mfcc_plan *plan);
+int srx_mfcc_plan_bin_max(const srx_mfcc_plan *plan);
+
+/* Frame count of the do/while(window.slide()) loop, src/mfcc.cpp:261-271 + src/clip.cpp:108-112:
+ * n = 1 + floor((L - wl - 1)/hop) for L > wl.  Fills frame_off[n_utt+1] (prefix sums) from
+ * sample_off[n_utt+1].  Returns SRX_ERR_INVALID if an utterance has L <= wl (the reference
+ * reads past its buffer there). */
+int srx_mfcc_frame_offsets(const srx_mfcc_cfg *cfg, const int64_t *sample_off, int n_utt, int64_t *frame_off);
+
+/* write_features(Clip, wl, hop, fb, fname) minus the file I/O (src/mfcc.cpp:235-275) for a
+ * ragged batch: utterance u owns samples[sample_off[u] .. sample_off[u+1]) and produces
+ * ceps[frame_off[u] .. frame_off[u+1])[n_ceps].  The samples are NOT modified (the
+ * reference mutates them in place; normalisation and pre-emphasis are fused into the frame
+ * load here -- use srx_normalize_volume_dev / srx_preemphasis_dev to reproduce the mutation).
+ * `scratch_scale_dev`: n_utt floats of device scratch (per-utterance gain). */
+int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev,
+                       const int64_t *sample_off_dev, int n_utt, const int64_t *frame_off_dev,
+                       int64_t total_frames, float *scratch_scale_dev, float *ceps_dev);
+/* Host-pointer convenience form (allocates, copies, runs, copies back). */
+int srx_mfcc_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples, const int64_t *sample_off,
+                   int n_utt, float *ceps, int64_t *frame_off);
+
+/* Clip::rmsAmplitude + Clip::normalizeVolume  src/clip.cpp:151-164 (in place, per utterance) */
+int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt,
+                             float target_rms, float *scratch_scale_dev);
+/* Clip::preemphasis  src/clip.cpp:199-205 (in place, per utterance; needs a same-size scratch) */
+int srx_preemphasis_dev(srx_ctx *ctx, float *samples_dev, float *scratch_dev, const int64_t *sample_off_dev,
+                        int n_utt, int64_t total_samples, float alpha);
+
+/* read_features smoothing + compute_deltas  src/mfcc.cpp:296-312, 73-102:
+ * ceps [total_frames][n_ceps] -> feats [total_frames][3*n_ceps] = [coeffs|deltas|delta2s]. */
+int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const float *ceps_dev, const int64_t *frame_off_dev,
+                           int n_utt, int64_t total_frames, float *feats_dev);
+int srx_features_batch(srx_ctx *ctx, int WL, int n_ceps, const float *ceps, const int64_t *frame_off, int n_utt,
+                       float *feats);
+
+/* mean(ut) / variance(ut, mu)  src/utterance.cpp:32-65 over the first D dims. */
+int srx_corpus_mean_var_dev(srx_ctx *ctx, const float *feats_dev, int ld, int64_t total_frames, int D,
+                            double *sum_dev /*[2*D] scratch+result: sums then sum of squares*/);
+
+/* ---------------------------------------------------------------- acoustic model ---- */
+typedef struct srx_model srx_model;
+
+typedef enum {
+    SRX_MIX_COMPONENT0 = 0, /* gmm::operator() as written: component 0 only (src/gmm.cpp:99-100) */
+    SRX_MIX_LOGSUMEXP = 1   /* the commented-out intent, log sum_m exp(g_m) (src/gmm.cpp:103-107) */
+} srx_mix_mode;
+
+/* acoustic_model: G tied states x M diagonal Gaussians x D dims (src/gmm.hpp:25-94).
+ * mean/var are [G][M][D] doubles (the reference keeps 80-bit long double), weight [G][M]. */
+int srx_model_create(srx_ctx *ctx, int G, int M, int D, srx_model **out);
+void srx_model_destroy(srx_model *m);
+int srx_model_set(srx_model *m, const double *mean, const double *var, const float *weight);
+int srx_model_get(srx_model *m, double *mean, double *var, float *weight);
+int srx_model_copy(srx_model *dst, const srx_model *src); /* acoustic_model(acoustic_model*) src/gmm.cpp:171-175 */
+
+typedef enum {
+    SRX_SCORE_MFMA = 0,  /* f32 MFMA contraction over [x^2, x, 1] (fast path) */
+    SRX_SCORE_EXACT = 1  /* per-dimension evaluation in the reference's operation order (f64 for long double) */
+} srx_score_path;
+
+/* acoustic_model::operator()(fv, ctx) for every frame and every tied state
+ * (src/gmm.cpp:41-49, 99-109, 184-186): out[t][g], ld_out >= G. */
+int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
+                      int64_t T, float *out_dev, int64_t ld_out);
+int srx_gmm_score(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats, int ld, int64_t T,
+                  float *out);
+
+/* ---------------------------------------------------------------- HMM / Viterbi ------ */
+/* hmm::hmm(vector<phone>, acoustic_model*)  src/hmm.cpp:56-88 (USE_SUBPHONES false): host helper.
+ * phones[S] (0 = SIL) -> ntr[S], trlogp[S][3] (targets s, s+1, s+2), ctx[S][3] (prev,curr,next). */
+int srx_hmm_build_training(const int32_t *phones, int S, int32_t *ntr, float *trlogp, int32_t *ctx);
+
+/* A ragged batch of left-to-right training HMMs (device pointers).  Utterance u owns
+ * states [state_off[u], state_off[u+1]) and frames [frame_off[u], frame_off[u+1]). */
+typedef struct {
+    int n_utt;
+    const int64_t *frame_off_dev; /* [n_utt+1] */
+    const int32_t *state_off_dev; /* [n_utt+1] */
+    const int32_t *tied_dev;      /* [n_states] column of the emission matrix for each state */
+    const int32_t *ntr_dev;       /* [n_states] 1..3 */
+    float *trlogp_dev;            /* [n_states][3] (mutated by srx_train_transitions_dev) */
+    int max_states;               /* max over utterances of S (host-known; <= 256) */
+} srx_hmm_batch;
+
+/* hmm::viterbi  src/hmm.cpp:150-224 for every utterance of the batch, emission scores given:
+ * emis[t*ld_emis + tied[s]] = (*acm)(*fvs[t], states[s].ctx).  Outputs: path[total_frames]
+ * (state index within the utterance), final_logp[n_utt] (= curr[best]), status[n_utt]
+ * (0 ok, 1 "NO PATH": path/final untouched).  prevp of the reference = final_logp / T.
+ * Score is bit-exact w.r.t. the reference's f32 add order (it accumulates logp across a source's
+ * transitions, src/hmm.cpp:164-169); exact ties are resolved towards the higher source index
+ * (the reference's order is unordered_map iteration order, i.e. unspecified).
+ * beam_width >= 1e10 (the reference default, src/hmm.cpp:150) disables the beam test. */
+int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t ld_emis,
+                          float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
+
+/* hmm::train_transition_probabilities  src/hmm.cpp:229-243 (+ set/get_adv_prob :26-35) for every
+ * utterance whose status is 0. */
+int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,
+                              const int32_t *status_dev);
+
+/* ---------------------------------------------------------------- embedded training -- */
+/* The statistics half of one EM iteration, hmm::train src/hmm.cpp:274-341, split at the two
+ * points where ranks must exchange sums.  A = model the statistics are taken
+ * under (hmm::acm), B = model rebuilt (hmm::temp_acm).  gid[t] = tied state of aligned frame t
+ * (-1: frame skipped, e.g. NO PATH utterance).
+ *   1. srx_em_shift_dev      per-state max log-density  -> shift[G]      (all-reduce MAX)
+ *   2. srx_em_pass1_dev      zeta sums and zeta*x sums  -> stats1[G*M*(1+D)] f64 (all-reduce SUM)
+ *   3. srx_em_means_dev      weights + means of B from stats1
+ *   4. srx_em_pass2_dev      zeta*(x-mean_B)^2 sums     -> stats2[G*M*D] f64     (all-reduce SUM)
+ *   5. srx_em_finish_dev     variances of B, then B = keep*B + (1-keep)*A (gaussian::blend)
+ * zeta is computed as w*exp(logp - shift[g]) in f64 (the reference uses unshifted 80-bit values;
+ * every quantity it derives from them is a ratio that the shift cancels). */
+int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,
+                          const int32_t *status_dev, int64_t total_frames, int32_t *gid_dev);
+int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
+                     float *logp_dev /*[T][M] out*/, float *shift_dev /*[G] out*/);
+int srx_em_pass1_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
+                     const float *logp_dev, const float *shift_dev, double *stats1_dev);
+int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1_dev);
+int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const float *feats_dev, int ld,
+                     const int32_t *gid_dev, int64_t T, const float *logp_dev, const float *shift_dev,
+                     double *stats2_dev);
+int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats1_dev, const double *stats2_dev,
+                      float blend_keep);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H */

@@ -1,0 +1,83 @@
+// Internal shared definitions for libsrx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/srx.h"
+
+struct srx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    char err[512] = {0};
+    // grow-only device workspace (Viterbi back-pointer words, ...)
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+// Returns a device workspace of at least `bytes` (contents undefined).  Grow-only, owned by ctx.
+int srx_workspace(srx_ctx *ctx, size_t bytes, void **out);
+
+extern char g_srx_create_err[512];
+
+static inline int srx_fail(srx_ctx *ctx, int code, const char *fmt, ...) {
+    char *dst = ctx ? ctx->err : g_srx_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define SRX_HIP(ctx, call)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e__ = (call);                                                                             \
+        if (e__ != hipSuccess)                                                                               \
+            return srx_fail((ctx), e__ == hipErrorOutOfMemory ? SRX_ERR_NOMEM : SRX_ERR_DEVICE,              \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__);     \
+    } while (0)
+
+#define SRX_REQUIRE(ctx, cond, ...)                                    \
+    do {                                                               \
+        if (!(cond)) return srx_fail((ctx), SRX_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define SRX_LAUNCH_CHECK(ctx) SRX_HIP(ctx, hipGetLastError())
+
+// RAII device buffer for the host-pointer convenience entry points.
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T>
+    T *as() {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Model storage (device-resident, double precision master copy + packed f32 MFMA operand).
+struct srx_model {
+    srx_ctx *ctx = nullptr;
+    int G = 0, M = 0, D = 0;
+    double *mean = nullptr;    // [G][M][D]
+    double *var = nullptr;     // [G][M][D]
+    float *weight = nullptr;   // [G][M]
+    float *logwt = nullptr;    // [G][M]  logf(weight)
+    // packed operand for the MFMA scoring kernel (rebuilt lazily when dirty)
+    float *packed = nullptr;   // see srx_gmm.hip
+    float *center = nullptr;   // [D] centring vector (f32)
+    int packed_mode = -1;      // mix mode the packing was built for
+    bool dirty = true;
+    size_t packed_bytes = 0;
+};

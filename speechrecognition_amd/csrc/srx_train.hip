@@ -1,0 +1,250 @@
+// Embedded-training sufficient statistics on gfx950.
+//
+// Replaces the statistics half of hmm::train (src/hmm.cpp:274-341): the zeta pass (:274-287),
+// sum_zetas/clear/weights (:288-296), the mean pass (:298-317), the variance pass (:319-339) and
+// gaussian::blend (src/gmm.cpp:82-88).  The reference walks every utterance sequentially and
+// re-evaluates gaussian::prob three times per aligned frame; here the per-frame log-densities are
+// evaluated once (in the reference's operation order, f64 for long double), kept, and the three
+// accumulations run frame-parallel with f64 atomics -- LDS-privatised per workgroup when the table
+// fits, straight to HBM otherwise.  zeta = w * exp(logp - shift[g]) with shift[g] the largest
+// log-density seen for tied state g: every statistic the reference derives is a ratio of zeta sums of
+// one state, so the shift cancels while keeping exp() inside f64 range.
+#include <cmath>
+
+#include "srx_common.h"
+
+__device__ __forceinline__ float logprob_exact(const float *__restrict__ fv, const double *__restrict__ mean,
+                                               const double *__restrict__ var, float logwt, int D) {
+    // gaussian::operator()  src/gmm.cpp:41-49
+    float res = 0.0f;
+    const float l2pi = (float)-0.4515827052894549;
+    for (int i = 0; i < D; i++) {
+        float t = (float)((double)fv[i] - mean[i]);
+        float tt = t * t;
+        double term = ((double)l2pi + log(var[i])) + (double)tt / var[i];
+        res = (float)((double)res + term);
+    }
+    float h = -0.5f * res;
+    return h + logwt;
+}
+
+__device__ __forceinline__ void atomic_max_float(float *addr, float v) {
+    // total order trick: non-negative floats order like ints, negative floats reversed like uints
+    if (v >= 0.0f)
+        atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
+    else
+        atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void k_gather_gid(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
+                                                    const int32_t *__restrict__ tied, const int32_t *__restrict__ path,
+                                                    const int32_t *__restrict__ status, int64_t total, int32_t *__restrict__ gid) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total) return;
+    int lo = 0, hi = n_utt;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (foff[mid] <= f) lo = mid; else hi = mid;
+    }
+    gid[f] = status[lo] == 0 ? tied[soff[lo] + path[f]] : -1;
+}
+
+__global__ void k_fill_f32(float *p, float v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// one thread per (frame, component): log-density under A, and the per-state maximum
+__global__ __launch_bounds__(256) void k_em_logp(const float *__restrict__ feats, int ld, const int32_t *__restrict__ gid, int64_t T,
+                                                 int M, int D, const double *__restrict__ mean, const double *__restrict__ var,
+                                                 const float *__restrict__ logwt, float *__restrict__ logp, float *__restrict__ shift) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * M) return;
+    const int64_t t = idx / M;
+    const int m = (int)(idx - t * M);
+    const int g = gid[t];
+    if (g < 0) { logp[idx] = 0.0f; return; }
+    const size_t o = (size_t)g * M + m;
+    const float lp = logprob_exact(feats + t * ld, mean + o * D, var + o * D, logwt[o], D);
+    logp[idx] = lp;
+    if (lp == lp) atomic_max_float(&shift[g], lp);
+}
+
+// Accumulation.  PASS 1: row o = [zeta, zeta*x_0 .. zeta*x_{D-1}] (stride 1+D).
+//                PASS 2: row o = [zeta*diff_d^2] (stride D), diff = f32(x_d - meanB[o][d]) (src/hmm.cpp:331).
+// If the whole table fits the dynamic LDS it is privatised per workgroup (LOCAL), else atomics go to HBM.
+template <int PASS, bool LOCAL>
+__global__ __launch_bounds__(256) void k_em_accum(const float *__restrict__ feats, int ld, const int32_t *__restrict__ gid, int64_t T,
+                                                  int M, int D, int nrows, const float *__restrict__ weight,
+                                                  const float *__restrict__ logp, const float *__restrict__ shift,
+                                                  const double *__restrict__ meanB, double *__restrict__ stats) {
+    extern __shared__ double tab[];
+    const int stride = PASS == 1 ? 1 + D : D;
+    if (LOCAL) {
+        for (int i = threadIdx.x; i < nrows * stride; i += 256) tab[i] = 0.0;
+        __syncthreads();
+    }
+    double *dst = LOCAL ? tab : stats;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < T * M; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t = idx / M;
+        const int m = (int)(idx - t * M);
+        const int g = gid[t];
+        if (g < 0) continue;
+        const size_t o = (size_t)g * M + m;
+        // zeta = weight * prob  (src/hmm.cpp:282,307,328), shifted
+        const double zeta = (double)weight[o] * exp((double)logp[idx] - (double)shift[g]);
+        const float *fv = feats + t * ld;
+        double *row = dst + o * stride;
+        if (PASS == 1) {
+            atomicAdd(&row[0], zeta);
+            for (int e = 0; e < D; e++) atomicAdd(&row[1 + e], zeta * (double)fv[e]);
+        } else {
+            for (int e = 0; e < D; e++) {
+                const float diff = (float)((double)fv[e] - meanB[o * D + e]);
+                atomicAdd(&row[e], zeta * (double)diff * (double)diff);
+            }
+        }
+    }
+    if (LOCAL) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nrows * stride; i += 256) {
+            const double v = tab[i];
+            if (v != 0.0) atomicAdd(&stats[i], v);
+        }
+    }
+}
+
+// weights and means of B from stats1  (src/hmm.cpp:288-296, 317; gaussian::clear sets var = 0)
+__global__ __launch_bounds__(256) void k_em_means(int G, int M, int D, const double *__restrict__ stats1, double *__restrict__ meanB,
+                                                  double *__restrict__ varB, float *__restrict__ wB, float *__restrict__ lwB) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)G * M * D) return;
+    const int e = (int)(idx % D);
+    const size_t o = (size_t)(idx / D);
+    const int g = (int)(o / M);
+    const double zs = stats1[o * (1 + D)];
+    meanB[idx] = stats1[o * (1 + D) + 1 + e] / zs;
+    varB[idx] = 0.0;
+    if (e == 0) {
+        double zg = 0.0;
+        for (int m = 0; m < M; m++) zg += stats1[((size_t)g * M + m) * (1 + D)];
+        const float w = (float)(zs / zg);
+        wB[o] = w;
+        lwB[o] = logf(w);
+    }
+}
+
+// variances of B, then gaussian::blend(A, keep)  (src/hmm.cpp:339-341, src/gmm.cpp:82-88)
+__global__ __launch_bounds__(256) void k_em_finish(int G, int M, int D, const double *__restrict__ stats1,
+                                                   const double *__restrict__ stats2, const double *__restrict__ meanA,
+                                                   const double *__restrict__ varA, const float *__restrict__ wA,
+                                                   double *__restrict__ meanB, double *__restrict__ varB, float *__restrict__ wB,
+                                                   float *__restrict__ lwB, float keep) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)G * M * D) return;
+    const int e = (int)(idx % D);
+    const size_t o = (size_t)(idx / D);
+    const double zs = stats1[o * (1 + D)];
+    const double vnew = stats2[idx] / zs;
+    const float omk = 1 - keep;
+    meanB[idx] = meanB[idx] * (double)keep + meanA[idx] * (double)omk;
+    varB[idx] = vnew * (double)keep + varA[idx] * (double)omk;
+    if (e == 0) {
+        const float a = wB[o] * keep;
+        const float b = wA[o] * omk;
+        const float w = a + b;
+        wB[o] = w;
+        lwB[o] = logf(w);
+    }
+}
+
+extern "C" int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev, const int32_t *status_dev,
+                                     int64_t total_frames, int32_t *gid_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_em_gather_gid_dev: null ctx");
+    SRX_REQUIRE(ctx, hmm && path_dev && status_dev && gid_dev && total_frames >= 0, "srx_em_gather_gid_dev: bad argument");
+    if (total_frames == 0 || hmm->n_utt == 0) return SRX_OK;
+    hipLaunchKernelGGL(k_gather_gid, dim3((unsigned)ceil_div64(total_frames, 256)), dim3(256), 0, ctx->stream, hmm->n_utt,
+                       hmm->frame_off_dev, hmm->state_off_dev, hmm->tied_dev, path_dev, status_dev, total_frames, gid_dev);
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
+                                float *logp_dev, float *shift_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_em_shift_dev: null ctx");
+    SRX_REQUIRE(ctx, A && feats_dev && gid_dev && logp_dev && shift_dev && T >= 0 && ld >= A->D, "srx_em_shift_dev: bad argument");
+    hipLaunchKernelGGL(k_fill_f32, dim3((A->G + 255) / 256), dim3(256), 0, ctx->stream, shift_dev, -__builtin_huge_valf(), A->G);
+    SRX_LAUNCH_CHECK(ctx);
+    if (T == 0) return SRX_OK;
+    const int64_t n = T * A->M;
+    SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_em_shift_dev: too large");
+    hipLaunchKernelGGL(k_em_logp, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats_dev, ld, gid_dev, T, A->M, A->D,
+                       A->mean, A->var, A->logwt, logp_dev, shift_dev);
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+template <int PASS>
+static int launch_accum(srx_ctx *ctx, srx_model *A, srx_model *B, const float *feats, int ld, const int32_t *gid, int64_t T,
+                        const float *logp, const float *shift, double *stats) {
+    const int stride = PASS == 1 ? 1 + A->D : A->D;
+    const int nrows = A->G * A->M;
+    const size_t bytes = (size_t)nrows * stride * sizeof(double);
+    SRX_HIP(ctx, hipMemsetAsync(stats, 0, bytes, ctx->stream));
+    if (T == 0) return SRX_OK;
+    const int64_t n = T * A->M;
+    int64_t nb = ceil_div64(n, 256 * 8);
+    if (nb > 8 * ctx->num_cus) nb = 8 * ctx->num_cus;
+    if (nb < 1) nb = 1;
+    const double *meanB = B ? B->mean : nullptr;
+    if (bytes <= 64 * 1024) {
+        hipLaunchKernelGGL((k_em_accum<PASS, true>), dim3((unsigned)nb), dim3(256), bytes, ctx->stream, feats, ld, gid, T, A->M, A->D,
+                           nrows, A->weight, logp, shift, meanB, stats);
+    } else {
+        hipLaunchKernelGGL((k_em_accum<PASS, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, feats, ld, gid, T, A->M, A->D,
+                           nrows, A->weight, logp, shift, meanB, stats);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+extern "C" int srx_em_pass1_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
+                                const float *logp_dev, const float *shift_dev, double *stats1_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_em_pass1_dev: null ctx");
+    SRX_REQUIRE(ctx, A && feats_dev && gid_dev && logp_dev && shift_dev && stats1_dev && T >= 0 && ld >= A->D,
+                "srx_em_pass1_dev: bad argument");
+    return launch_accum<1>(ctx, A, nullptr, feats_dev, ld, gid_dev, T, logp_dev, shift_dev, stats1_dev);
+}
+
+extern "C" int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_em_means_dev: null ctx");
+    SRX_REQUIRE(ctx, B && stats1_dev, "srx_em_means_dev: null argument");
+    const int64_t n = (int64_t)B->G * B->M * B->D;
+    hipLaunchKernelGGL(k_em_means, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev, B->mean,
+                       B->var, B->weight, B->logwt);
+    SRX_LAUNCH_CHECK(ctx);
+    B->dirty = true;
+    return SRX_OK;
+}
+
+extern "C" int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const float *feats_dev, int ld, const int32_t *gid_dev,
+                                int64_t T, const float *logp_dev, const float *shift_dev, double *stats2_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_em_pass2_dev: null ctx");
+    SRX_REQUIRE(ctx, A && B && feats_dev && gid_dev && logp_dev && shift_dev && stats2_dev && T >= 0 && ld >= A->D,
+                "srx_em_pass2_dev: bad argument");
+    SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_pass2_dev: model shape mismatch");
+    return launch_accum<2>(ctx, A, B, feats_dev, ld, gid_dev, T, logp_dev, shift_dev, stats2_dev);
+}
+
+extern "C" int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats1_dev, const double *stats2_dev,
+                                 float blend_keep) {
+    SRX_REQUIRE(nullptr, ctx, "srx_em_finish_dev: null ctx");
+    SRX_REQUIRE(ctx, A && B && stats1_dev && stats2_dev, "srx_em_finish_dev: null argument");
+    SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_finish_dev: model shape mismatch");
+    const int64_t n = (int64_t)B->G * B->M * B->D;
+    hipLaunchKernelGGL(k_em_finish, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev,
+                       stats2_dev, A->mean, A->var, A->weight, B->mean, B->var, B->weight, B->logwt, blend_keep);
+    SRX_LAUNCH_CHECK(ctx);
+    B->dirty = true;
+    return SRX_OK;
+}

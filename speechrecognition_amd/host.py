@@ -1,0 +1,321 @@
+"""Python host layer over the C ABI (include/srx.h).
+
+Names follow the reference's (mel_filterbank, write_features, read_features, acoustic_model, hmm
+viterbi / train): see SURVEY.md section 8b for the C++ surface they mirror.  The authoritative
+drop-in for the C++ callers is speechrecognition_amd/host/srx_host.hpp; this module exists so the
+parity tests, bench.py and the multi-GPU driver can call the same entry points from Python.
+Every computation here runs in libsrx.so on the GPU; numpy is used for marshalling only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import (SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP, SRX_SCORE_EXACT, SRX_SCORE_MFMA, check, srx_filter,
+                    srx_hmm_batch, srx_mfcc_cfg)
+
+FILTER_DT = np.dtype([("center", np.float32), ("width", np.float32), ("height", np.float32)])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """srx_ctx: one per GPU.  `stream` is a raw hipStream_t handle (int) or None."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _capi.load()
+        h = C.c_void_p()
+        check(self.lib.srx_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.srx_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        check(self.lib.srx_sync(self.h), self.h)
+
+    # --- device arrays ---
+    def empty(self, shape, dtype):
+        return DevArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        a = DevArray(self, shape, dtype)
+        check(self.lib.srx_memset(self.h, a.ptr, 0, a.nbytes), self.h)
+        return a
+
+    def array(self, host):
+        host = np.ascontiguousarray(host)
+        a = DevArray(self, host.shape, host.dtype)
+        a.upload(host)
+        return a
+
+
+class DevArray:
+    """A typed device allocation owned through srx_malloc/srx_free."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(v) for v in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(ctx.lib.srx_malloc(ctx.h, self.nbytes, C.byref(p)), ctx.h)
+        self.ptr = p
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        check(self.ctx.lib.srx_memcpy_h2d(self.ctx.h, self.ptr, _ptr(host), self.nbytes), self.ctx.h)
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        check(self.ctx.lib.srx_memcpy_d2h(self.ctx.h, _ptr(out), self.ptr, self.nbytes), self.ctx.h)
+        return out
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.ctx.lib.srx_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------- filterbank / MFCC
+def mel_filterbank(end=7200.0, n=48, dft_bins=320, sps=16000):
+    """mel_filterbank(end, n, dft_bins, sps)  src/mfcc.cpp:190-201 -> (filters, bin_max)."""
+    lib = _capi.load()
+    fb = np.zeros(n, dtype=FILTER_DT)
+    bm = C.c_int(0)
+    check(lib.srx_mel_filterbank(end, n, dft_bins, sps, fb.ctypes.data_as(C.POINTER(srx_filter)), C.byref(bm)))
+    return fb, bm.value
+
+
+def mfcc_config(window_len=320, frame_shift=160, n_ceps=13, normalize=True, target_rms=1.0, preemphasis=True,
+                alpha=0.96):
+    return srx_mfcc_cfg(window_len, frame_shift, n_ceps, int(normalize), target_rms, int(preemphasis), alpha)
+
+
+def frame_offsets(cfg, sample_off):
+    sample_off = np.ascontiguousarray(sample_off, dtype=np.int64)
+    n = len(sample_off) - 1
+    fo = np.zeros(n + 1, np.int64)
+    check(_capi.load().srx_mfcc_frame_offsets(C.byref(cfg), _ptr(sample_off), n, _ptr(fo)))
+    return fo
+
+
+class MfccPlan:
+    def __init__(self, ctx, cfg, fb):
+        self.ctx, self.cfg = ctx, cfg
+        fb = np.ascontiguousarray(fb, dtype=FILTER_DT)
+        h = C.c_void_p()
+        check(ctx.lib.srx_mfcc_plan_create(ctx.h, C.byref(cfg), fb.ctypes.data_as(C.POINTER(srx_filter)), len(fb),
+                                           C.byref(h)), ctx.h)
+        self.h = h
+        self.bin_max = ctx.lib.srx_mfcc_plan_bin_max(h)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.srx_mfcc_plan_destroy(self.h)
+            self.h = None
+
+    def write_features(self, samples, sample_off):
+        """Batch form of write_features (src/mfcc.cpp:235-275) on host arrays.
+        Returns (ceps [total_frames, n_ceps], frame_off)."""
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        sample_off = np.ascontiguousarray(sample_off, dtype=np.int64)
+        n = len(sample_off) - 1
+        fo = frame_offsets(self.cfg, sample_off)
+        ceps = np.zeros((int(fo[-1]), self.cfg.n_ceps), np.float32)
+        fo2 = np.zeros(n + 1, np.int64)
+        check(self.ctx.lib.srx_mfcc_batch(self.ctx.h, self.h, _ptr(samples), _ptr(sample_off), n, _ptr(ceps),
+                                          _ptr(fo2)), self.ctx.h)
+        assert (fo == fo2).all()
+        return ceps, fo
+
+    def write_features_dev(self, samples_d, sample_off_d, n_utt, frame_off_d, total_frames, scale_d, ceps_d):
+        check(self.ctx.lib.srx_mfcc_batch_dev(self.ctx.h, self.h, samples_d.ptr, sample_off_d.ptr, n_utt,
+                                              frame_off_d.ptr, total_frames, scale_d.ptr if scale_d else None,
+                                              ceps_d.ptr), self.ctx.h)
+
+
+def read_features(ctx, ceps, frame_off, WL=2):
+    """Smoothing + deltas of read_features (src/mfcc.cpp:296-312) on host arrays -> [T, 3*n_ceps]."""
+    ceps = np.ascontiguousarray(ceps, dtype=np.float32)
+    frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+    T, nc = ceps.shape
+    feats = np.zeros((T, 3 * nc), np.float32)
+    check(ctx.lib.srx_features_batch(ctx.h, WL, nc, _ptr(ceps), _ptr(frame_off), len(frame_off) - 1, _ptr(feats)), ctx.h)
+    return feats
+
+
+def read_features_dev(ctx, WL, n_ceps, ceps_d, frame_off_d, n_utt, total_frames, feats_d):
+    check(ctx.lib.srx_features_batch_dev(ctx.h, WL, n_ceps, ceps_d.ptr, frame_off_d.ptr, n_utt, total_frames,
+                                         feats_d.ptr), ctx.h)
+
+
+def normalize_volume(ctx, samples, sample_off, target=1.0):
+    """Clip::normalizeVolume (src/clip.cpp:151-154) per utterance; returns the scaled copy."""
+    x = ctx.array(np.ascontiguousarray(samples, np.float32))
+    so = ctx.array(np.ascontiguousarray(sample_off, np.int64))
+    n = len(sample_off) - 1
+    sc = ctx.empty((n,), np.float32)
+    check(ctx.lib.srx_normalize_volume_dev(ctx.h, x.ptr, so.ptr, n, target, sc.ptr), ctx.h)
+    return x.get()
+
+
+def preemphasis(ctx, samples, sample_off, alpha=0.96):
+    """Clip::preemphasis (src/clip.cpp:199-205) per utterance; returns the filtered copy."""
+    x = ctx.array(np.ascontiguousarray(samples, np.float32))
+    tmp = ctx.empty(x.shape, np.float32)
+    so = ctx.array(np.ascontiguousarray(sample_off, np.int64))
+    n = len(sample_off) - 1
+    check(ctx.lib.srx_preemphasis_dev(ctx.h, x.ptr, tmp.ptr, so.ptr, n, x.shape[0], alpha), ctx.h)
+    return x.get()
+
+
+def corpus_mean_var(ctx, feats, D):
+    """mean(ut), variance(ut, mu)  src/utterance.cpp:32-65."""
+    feats = np.ascontiguousarray(feats, np.float32)
+    T, ld = feats.shape
+    f = ctx.array(feats)
+    s = ctx.zeros((2 * D,), np.float64)
+    check(ctx.lib.srx_corpus_mean_var_dev(ctx.h, f.ptr, ld, T, D, s.ptr), ctx.h)
+    r = s.get()
+    mu = (r[:D].astype(np.float32) / np.float32(T)).astype(np.float32)
+    var = (r[D:] / T).astype(np.float32)
+    return mu, var
+
+
+# ----------------------------------------------------------------------------- acoustic model
+class AcousticModel:
+    """acoustic_model (src/gmm.hpp:75-94): G tied states x M diagonal Gaussians x D dims, device resident."""
+
+    def __init__(self, ctx, G, M, D):
+        self.ctx, self.G, self.M, self.D = ctx, G, M, D
+        h = C.c_void_p()
+        check(ctx.lib.srx_model_create(ctx.h, G, M, D, C.byref(h)), ctx.h)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.srx_model_destroy(self.h)
+            self.h = None
+
+    def set(self, mean, var, weight):
+        mean = np.ascontiguousarray(mean, np.float64).reshape(self.G, self.M, self.D)
+        var = np.ascontiguousarray(var, np.float64).reshape(self.G, self.M, self.D)
+        weight = np.ascontiguousarray(weight, np.float32).reshape(self.G, self.M)
+        check(self.ctx.lib.srx_model_set(self.h, _ptr(mean), _ptr(var), _ptr(weight)), self.ctx.h)
+
+    def get(self):
+        mean = np.zeros((self.G, self.M, self.D), np.float64)
+        var = np.zeros_like(mean)
+        w = np.zeros((self.G, self.M), np.float32)
+        check(self.ctx.lib.srx_model_get(self.h, _ptr(mean), _ptr(var), _ptr(w)), self.ctx.h)
+        return mean, var, w
+
+    def copy_from(self, other):
+        check(self.ctx.lib.srx_model_copy(self.h, other.h), self.ctx.h)
+
+    def score(self, feats, mix_mode=SRX_MIX_COMPONENT0, path=SRX_SCORE_MFMA):
+        """acoustic_model::operator() for every frame x tied state, host arrays -> [T, G]."""
+        feats = np.ascontiguousarray(feats, np.float32)
+        T, ld = feats.shape
+        out = np.zeros((T, self.G), np.float32)
+        check(self.ctx.lib.srx_gmm_score(self.ctx.h, self.h, mix_mode, path, _ptr(feats), ld, T, _ptr(out)), self.ctx.h)
+        return out
+
+    def score_dev(self, feats_d, ld, T, out_d, ld_out, mix_mode=SRX_MIX_COMPONENT0, path=SRX_SCORE_MFMA):
+        check(self.ctx.lib.srx_gmm_score_dev(self.ctx.h, self.h, mix_mode, path, feats_d.ptr, ld, T, out_d.ptr, ld_out),
+              self.ctx.h)
+
+
+# ----------------------------------------------------------------------------- HMM batch
+def build_training_hmm(phones):
+    """hmm::hmm(vector<phone>, acoustic_model*)  src/hmm.cpp:56-88 -> (ntr, trlogp[S,3], ctx[S,3])."""
+    phones = np.ascontiguousarray(phones, np.int32)
+    S = len(phones)
+    ntr = np.zeros(S, np.int32)
+    tr = np.zeros((S, 3), np.float32)
+    ctx3 = np.zeros((S, 3), np.int32)
+    check(_capi.load().srx_hmm_build_training(_ptr(phones), S, _ptr(ntr), _ptr(tr), _ptr(ctx3)))
+    return ntr, tr, ctx3
+
+
+class HmmBatch:
+    """A ragged batch of per-utterance training HMMs on the device (utterance.hmm of src/utterance.hpp:30)."""
+
+    def __init__(self, ctx, frame_off, ntr_list, trlogp_list, tied_list):
+        self.ctx = ctx
+        self.n_utt = len(ntr_list)
+        so = np.zeros(self.n_utt + 1, np.int32)
+        for u, n in enumerate(ntr_list):
+            so[u + 1] = so[u] + len(n)
+        self.state_off = so
+        self.frame_off = np.ascontiguousarray(frame_off, np.int64)
+        self.max_states = int(max(len(n) for n in ntr_list)) if self.n_utt else 1
+        self.frame_off_d = ctx.array(self.frame_off)
+        self.state_off_d = ctx.array(so)
+        self.tied_d = ctx.array(np.concatenate(tied_list).astype(np.int32))
+        self.ntr_d = ctx.array(np.concatenate(ntr_list).astype(np.int32))
+        self.trlogp_d = ctx.array(np.concatenate(trlogp_list).astype(np.float32).reshape(-1, 3))
+        self.total_frames = int(self.frame_off[-1])
+        self.c = srx_hmm_batch(self.n_utt, self.frame_off_d.ptr, self.state_off_d.ptr, self.tied_d.ptr, self.ntr_d.ptr,
+                               self.trlogp_d.ptr, self.max_states)
+
+    def trlogp(self):
+        return self.trlogp_d.get()
+
+    def viterbi(self, emis_d, ld_emis, beam=1e10, path_d=None, final_d=None, status_d=None):
+        """hmm::viterbi for every utterance (src/hmm.cpp:150-224), emission matrix on the device."""
+        ctx = self.ctx
+        path_d = path_d or ctx.zeros((max(self.total_frames, 1),), np.int32)
+        final_d = final_d or ctx.zeros((max(self.n_utt, 1),), np.float32)
+        status_d = status_d or ctx.zeros((max(self.n_utt, 1),), np.int32)
+        check(ctx.lib.srx_viterbi_batch_dev(ctx.h, C.byref(self.c), emis_d.ptr, ld_emis, beam, path_d.ptr, final_d.ptr,
+                                            status_d.ptr), ctx.h)
+        return path_d, final_d, status_d
+
+    def train_transition_probabilities(self, path_d, status_d):
+        check(self.ctx.lib.srx_train_transitions_dev(self.ctx.h, C.byref(self.c), path_d.ptr, status_d.ptr), self.ctx.h)
+
+
+# ----------------------------------------------------------------------------- EM statistics
+def em_statistics(ctx, A, B, feats_d, ld, gid_d, T, blend_keep=0.2, allreduce_max=None, allreduce_sum=None):
+    """The statistics half of one hmm::train iteration (src/hmm.cpp:274-341): rebuilds model B from the
+    alignment gid under model A.  `allreduce_*` are optional callables taking a DevArray (multi-GPU
+    exchange points); None on a single GPU."""
+    lib = ctx.lib
+    G, M, D = A.G, A.M, A.D
+    logp = ctx.empty((max(T * M, 1),), np.float32)
+    shift = ctx.empty((G,), np.float32)
+    stats1 = ctx.empty((G * M * (1 + D),), np.float64)
+    stats2 = ctx.empty((G * M * D,), np.float64)
+    check(lib.srx_em_shift_dev(ctx.h, A.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr, shift.ptr), ctx.h)
+    if allreduce_max:
+        allreduce_max(shift)
+    check(lib.srx_em_pass1_dev(ctx.h, A.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr, shift.ptr, stats1.ptr), ctx.h)
+    if allreduce_sum:
+        allreduce_sum(stats1)
+    check(lib.srx_em_means_dev(ctx.h, B.h, stats1.ptr), ctx.h)
+    check(lib.srx_em_pass2_dev(ctx.h, A.h, B.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr, shift.ptr, stats2.ptr), ctx.h)
+    if allreduce_sum:
+        allreduce_sum(stats2)
+    check(lib.srx_em_finish_dev(ctx.h, A.h, B.h, stats1.ptr, stats2.ptr, blend_keep), ctx.h)
+    ctx.sync()
+    return stats1, stats2, shift
+
+
+def gather_gid(ctx, hmm, path_d, status_d):
+    gid = ctx.empty((max(hmm.total_frames, 1),), np.int32)
+    check(ctx.lib.srx_em_gather_gid_dev(ctx.h, C.byref(hmm.c), path_d.ptr, status_d.ptr, hmm.total_frames, gid.ptr), ctx.h)
+    return gid

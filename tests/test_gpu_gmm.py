@@ -1,0 +1,102 @@
+"""Parity of GMM emission scoring (acoustic_model::operator(), src/gmm.cpp:41-49,99-109,184-186).
+
+Tolerance rule (north_star: log-likelihoods within 1e-4 relative): |a-b| <= 1e-4 * max(|a|, |b|, 1).
+The EXACT path reproduces the reference's per-dimension f32 accumulation with f64 in place of the
+80-bit long double and is expected to be bit-identical to the oracle (allowing a 1-ulp slip where
+f64 vs f80 rounding of a term lands on an f32 rounding boundary)."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP, SRX_SCORE_EXACT, SRX_SCORE_MFMA, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=1e-4):
+    return np.abs(a - b) <= tol * np.maximum(np.maximum(np.abs(a), np.abs(b)), 1.0)
+
+
+def _feats(T, ld, seed, scale=1.3, offset=0.0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((T, ld)) * scale + offset).astype(np.float32)
+
+
+def test_reference_native_shape_D13_M1_G40(ctx, oracle):
+    G, M, D = 40, 1, 13
+    mean, var, w = synth.random_model(G, M, D, 1)
+    w[:] = 1.0
+    feats = _feats(777, 39, 2)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    ref = oracle.gmm_score(feats, mean, var, np.log(w), D, 0)
+    exact = model.score(feats, SRX_MIX_COMPONENT0, SRX_SCORE_EXACT)
+    ulp = np.abs(exact.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, ulp.max()
+    assert (ulp == 0).mean() > 0.999
+    fast = model.score(feats, SRX_MIX_COMPONENT0, SRX_SCORE_MFMA)
+    assert _close(fast, ref).all(), np.abs(fast - ref).max()
+    model.close()
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 8, 16])
+def test_mixtures_D39_logsumexp(ctx, oracle, M):
+    G, D = 70, 39
+    mean, var, w = synth.random_model(G, M, D, 10 + M)
+    feats = _feats(300, 39, 3)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    lw = np.log(w).astype(np.float32)
+    for mode in (SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP):
+        ref = oracle.gmm_score(feats, mean, var, lw, D, mode)
+        fast = model.score(feats, mode, SRX_SCORE_MFMA)
+        assert _close(fast, ref).all(), (mode, np.abs(fast - ref).max())
+        exact = model.score(feats, mode, SRX_SCORE_EXACT)
+        assert _close(exact, ref, 1e-6).all(), (mode, np.abs(exact - ref).max())
+    model.close()
+
+
+def test_offset_features_and_stress_rows(ctx, oracle):
+    """Large common offset (raw cepstra are not centred) and the survey's stress rows:
+    tiny variance, |x - mu| = 30."""
+    G, M, D = 33, 1, 13
+    rng = np.random.default_rng(4)
+    mean = rng.standard_normal((G, M, D)) + 50.0
+    var = rng.uniform(0.5, 1.5, (G, M, D))
+    var[0] = 1e-4
+    w = np.ones((G, M), np.float32)
+    feats = _feats(200, 39, 5, 1.0, 50.0)
+    feats[0, :13] = mean[1, 0] + 30.0
+    feats[1, :13] = mean[0, 0] + 0.003
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    ref = oracle.gmm_score(feats, mean, var, np.zeros_like(w), D, 0)
+    fast = model.score(feats, SRX_MIX_COMPONENT0, SRX_SCORE_MFMA)
+    assert _close(fast, ref).all(), np.abs(fast - ref).max()
+    model.close()
+
+
+def test_ragged_T_and_ld(ctx, oracle):
+    G, M, D = 5, 2, 7
+    mean, var, w = synth.random_model(G, M, D, 6)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    for T in (1, 127, 128, 129, 1000):
+        feats = _feats(T, 9, T)
+        ref = oracle.gmm_score(feats, mean, var, np.log(w), D, 1)
+        fast = model.score(feats, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA)
+        assert _close(fast, ref).all()
+    assert model.score(np.zeros((0, 9), np.float32)).shape == (0, G)
+    model.close()
+
+
+def test_model_roundtrip_and_copy(ctx):
+    G, M, D = 6, 3, 13
+    mean, var, w = synth.random_model(G, M, D, 8)
+    a = host.AcousticModel(ctx, G, M, D)
+    b = host.AcousticModel(ctx, G, M, D)
+    a.set(mean, var, w)
+    b.copy_from(a)
+    m2, v2, w2 = b.get()
+    assert np.array_equal(m2, mean) and np.array_equal(v2, var) and np.array_equal(w2, w)
+    a.close()
+    b.close()

@@ -1,0 +1,137 @@
+"""Parity of the HIP MFCC / feature path against the CPU oracle (oracle/srx_oracle.c).
+
+Tolerances (north_star: "MFCCs ... within 1e-4 relative"): cepstra of one frame are compared against the
+frame's own cepstral scale, |a-b| <= 1e-4 * max_j |ref_j|; element-wise relative error is meaningless for
+the DCT's near-cancelling higher coefficients.  Integer-like / pure-f32 stages are bit-exact."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame_rel_err(got, ref):
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-30)
+    return (np.abs(got - ref) / scale).max()
+
+
+def _oracle_batch(O, x, off, wl, hop, fb, nparams=13, normalize=True):
+    outs = []
+    for u in range(len(off) - 1):
+        xu = x[off[u]:off[u + 1]]
+        if normalize:
+            xu = O.normalize_volume(xu)
+        c, _ = O.write_features(xu, wl, hop, fb, nparams)
+        outs.append(c)
+    return np.concatenate(outs)
+
+
+@pytest.mark.parametrize("wl,hop", [(320, 160), (400, 160)])
+def test_mfcc_ragged_batch_parity(ctx, oracle, wl, hop):
+    rng = np.random.default_rng(1)
+    lens = [wl + 1, wl + hop + 1, 2 * wl, 16000, 5000, wl + 2 * hop, 23456]
+    off = np.zeros(len(lens) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    x = np.concatenate([synth.utterance_audio(100 + i, n) for i, n in enumerate(lens)])
+    x[off[3]:off[4]] = (0.5 * rng.standard_normal(16000)).clip(-1, 1)  # white noise utterance
+    fb, bin_max = host.mel_filterbank(7200, 48, wl, 16000)
+    fbo, bmo = oracle.mel_filterbank(7200, 48, wl, 16000)
+    assert bin_max == bmo and fb.tobytes() == fbo.tobytes()
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop), fb)
+    ceps, fo = plan.write_features(x, off)
+    assert [int(v) for v in np.diff(fo)] == [oracle.num_frames(n, wl, hop) for n in lens]
+    ref = _oracle_batch(oracle, x, off, wl, hop, fbo)
+    assert ceps.shape == ref.shape
+    err = _frame_rel_err(ceps, ref)
+    assert err <= 1e-4, err
+    plan.close()
+
+
+def test_mfcc_single_5s_wav_config0(ctx, oracle):
+    """BASELINE config 0: one 5 s 16 kHz clip, 320/160, 498 frames."""
+    t = np.arange(80000) / 16000.0
+    rng = np.random.default_rng(12345)
+    x = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 1800 * t) + 0.1 * (rng.random(80000) - 0.5))
+    x = (np.round(x * 32767).astype(np.int16) / 32768.0).astype(np.float32)  # 16-bit PCM round trip, src/wav.cpp:41-44
+    off = np.array([0, 80000], np.int64)
+    fb, _ = host.mel_filterbank(7200, 48, 320, 16000)
+    plan = host.MfccPlan(ctx, host.mfcc_config(320, 160), fb)
+    ceps, fo = plan.write_features(x, off)
+    assert fo[1] == 498
+    ref = _oracle_batch(oracle, x, off, 320, 160, fb)
+    assert _frame_rel_err(ceps, ref) <= 1e-4
+    plan.close()
+
+
+def test_mfcc_no_normalize_no_preemph(ctx, oracle):
+    x = synth.utterance_audio(7, 4000)
+    off = np.array([0, 4000], np.int64)
+    fb, _ = host.mel_filterbank(7200, 48, 320, 16000)
+    plan = host.MfccPlan(ctx, host.mfcc_config(320, 160, normalize=False, preemphasis=False), fb)
+    ceps, _ = plan.write_features(x, off)
+    # oracle: window+DFT+filterbank+log+DCT only
+    n = oracle.num_frames(4000, 320, 160)
+    ref = np.zeros((n, 13), np.float32)
+    import ctypes as C
+    for f in range(n):
+        fr = np.ascontiguousarray(x[f * 160:f * 160 + 320])
+        oracle.lib().orc_mfcc_frame(fr, 320, fb.ctypes.data, 48, 13, ref[f], None)
+    assert _frame_rel_err(ceps, ref) <= 1e-4
+    plan.close()
+
+
+def test_mirrored_bins_near_nyquist(ctx, oracle):
+    """bin_max > N/2 takes the mirror branch of partial_dft (src/clip.cpp:177,186-192)."""
+    wl, hop = 64, 32
+    fb, bm = host.mel_filterbank(7200, 20, wl, 12000)  # top filter beyond N/2
+    assert bm > wl // 2
+    x = synth.utterance_audio(3, 3000)
+    off = np.array([0, 3000], np.int64)
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop), fb)
+    ceps, _ = plan.write_features(x, off)
+    ref = _oracle_batch(oracle, x, off, wl, hop, fb)
+    assert _frame_rel_err(ceps, ref) <= 1e-4
+    plan.close()
+
+
+def test_normalize_and_preemphasis_in_place_ops(ctx, oracle):
+    lens = [1000, 37, 5000]
+    off = np.zeros(4, np.int64)
+    off[1:] = np.cumsum(lens)
+    x = np.concatenate([synth.utterance_audio(i, n) for i, n in enumerate(lens)])
+    got = host.normalize_volume(ctx, x, off, 1.0)
+    ref = np.concatenate([oracle.normalize_volume(x[off[u]:off[u + 1]]) for u in range(3)])
+    # f64 sum of squares in a different order: the gain may differ by an ulp
+    np.testing.assert_allclose(got, ref, rtol=2.5e-7, atol=0)
+    got = host.preemphasis(ctx, x, off, 0.96)
+    ref = np.concatenate([oracle.preemphasis(x[off[u]:off[u + 1]]) for u in range(3)])
+    assert got.tobytes() == ref.tobytes()  # pure f32: bit-exact
+
+
+def test_short_utterance_rejected(ctx):
+    fb, _ = host.mel_filterbank(7200, 48, 320, 16000)
+    plan = host.MfccPlan(ctx, host.mfcc_config(320, 160), fb)
+    x = np.zeros(320, np.float32)
+    with pytest.raises(Exception):
+        plan.write_features(x, np.array([0, 320], np.int64))
+    # empty batch is fine
+    c, fo = plan.write_features(np.zeros(0, np.float32), np.array([0], np.int64))
+    assert c.shape == (0, 13) and list(fo) == [0]
+    plan.close()
+
+
+@pytest.mark.parametrize("WL", [2, 1, 4])
+def test_features_smoothing_deltas_bit_exact(ctx, oracle, WL):
+    rng = np.random.default_rng(5)
+    lens = [1, 2, 3, 5, 9, 130, 498]
+    fo = np.zeros(len(lens) + 1, np.int64)
+    fo[1:] = np.cumsum(lens)
+    raw = rng.standard_normal((int(fo[-1]), 13)).astype(np.float32) * 3
+    got = host.read_features(ctx, raw, fo, WL)
+    ref = np.concatenate([oracle.read_features(raw[fo[u]:fo[u + 1]], WL) for u in range(len(lens))])
+    # n = 1 gives 0/0 = NaN deltas in the reference (src/mfcc.cpp:79): same pattern, same bits elsewhere
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    m = ~np.isnan(ref)
+    assert got[m].tobytes() == ref[m].tobytes()
+    assert np.isnan(ref[0, 13:]).all()

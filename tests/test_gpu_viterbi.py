@@ -1,0 +1,97 @@
+"""Parity of batched Viterbi forced alignment (hmm::viterbi, src/hmm.cpp:150-224) and
+train_transition_probabilities (src/hmm.cpp:229-243).
+
+Bar: final score bit-exact always; path bit-exact (the oracle is run with the same fixed tie order,
+and inputs are continuous random so exact ties on a decision are absent -- the oracle's tie counter
+is asserted)."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_batch(rng, n_utt, G, t_lo, t_hi, max_states=None, words=None):
+    phones, ntrs, trs, tieds, Ts = [], [], [], [], []
+    for _ in range(n_utt):
+        ph = synth.phone_string(rng, words, max_states)
+        ntr, tr, _ = host.build_training_hmm(ph)
+        phones.append(ph)
+        ntrs.append(ntr)
+        trs.append(tr)
+        tieds.append(rng.integers(0, G, len(ph)).astype(np.int32))
+        Ts.append(int(rng.integers(t_lo, t_hi)))
+    fo = np.zeros(n_utt + 1, np.int64)
+    fo[1:] = np.cumsum(Ts)
+    return phones, ntrs, trs, tieds, fo
+
+
+def _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam=1e10):
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    emis_d = ctx.array(emis)
+    path_d, final_d, status_d = hb.viterbi(emis_d, emis.shape[1], beam)
+    ctx.sync()
+    path, final, status = path_d.get(), final_d.get(), status_d.get()
+    for u in range(len(ntrs)):
+        e = emis[fo[u]:fo[u + 1]]
+        r = oracle.viterbi(e, tieds[u], ntrs[u], trs[u], beam, 0)
+        assert status[u] == r["status"], (u, status[u], r["status"])
+        if r["status"] == 0:
+            assert final[u].tobytes() == r["final"].tobytes(), (u, final[u], r["final"])
+            assert r["nties"] == 0
+            assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"]), u
+    return hb, path_d, status_d, path, status
+
+
+@pytest.mark.parametrize("words,spl", [(4, 1), (20, 2), (34, 4)])
+def test_viterbi_bit_exact(ctx, oracle, words, spl):
+    rng = np.random.default_rng(20 + spl)
+    G = 50
+    _, ntrs, trs, tieds, fo = _make_batch(rng, 24, G, 200, 800, max_states=64 * spl, words=words)
+    mx = max(len(n) for n in ntrs)
+    assert (mx > 64 * (spl // 2)) or spl == 1
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 20).astype(np.float32)
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis)
+
+
+def test_viterbi_positive_scores_and_short_T(ctx, oracle):
+    """Log-densities are routinely positive (log(2/pi) constant, src/gmm.cpp:43); T barely reaching the
+    last state, T too short (NO PATH, src/hmm.cpp:212-215), T = 1."""
+    rng = np.random.default_rng(31)
+    G = 40
+    ph = np.array([0, 5, 6, 0, 7, 8, 9, 0], np.int32)
+    ntr, tr, _ = host.build_training_hmm(ph)
+    Ts = [1, 3, 5, 6, 7, 8, 40]
+    fo = np.zeros(len(Ts) + 1, np.int64)
+    fo[1:] = np.cumsum(Ts)
+    n = len(Ts)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 3 + 12).astype(np.float32)
+    tieds = [rng.integers(0, G, len(ph)).astype(np.int32) for _ in range(n)]
+    _, _, _, path, status = _check(ctx, oracle, [ntr] * n, [tr] * n, tieds, fo, emis)
+    assert status[0] == 1 and status[-1] == 0 and status.sum() >= 2
+
+
+def test_viterbi_finite_beam(ctx, oracle):
+    rng = np.random.default_rng(41)
+    G = 30
+    _, ntrs, trs, tieds, fo = _make_batch(rng, 16, G, 100, 400, words=5)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 6 - 10).astype(np.float32)
+    for beam in (1e9, 200.0, 60.0, 25.0):
+        _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam)
+
+
+def test_train_transition_probabilities(ctx, oracle):
+    rng = np.random.default_rng(51)
+    G = 40
+    _, ntrs, trs, tieds, fo = _make_batch(rng, 12, G, 150, 500, words=6)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 15).astype(np.float32)
+    hb, path_d, status_d, path, status = _check(ctx, oracle, ntrs, trs, tieds, fo, emis)
+    for it in range(2):  # twice: the second update starts from non-default probabilities
+        hb.train_transition_probabilities(path_d, status_d)
+        ctx.sync()
+        got = hb.trlogp()
+        so = hb.state_off
+        for u in range(len(ntrs)):
+            trs[u] = oracle.train_transitions(path[fo[u]:fo[u + 1]], ntrs[u], trs[u])
+            np.testing.assert_allclose(got[so[u]:so[u + 1]], trs[u], rtol=3e-6, atol=1e-7)
