@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X acoustic pipeline (BASELINE.json metric: audio frames/sec through
+MFCC + GMM scoring + Viterbi forced alignment).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (driver, N > 1)
+
+One step = one pass of the whole hot path over one resident batch: BASELINE.json configs[1]'s corpus
+(1,000 synthetic Voxforge-shaped utterances, 2-8 s, 16 kHz) at the BASELINE shapes (25 ms / 10 ms
+frames, 13 cepstra + deltas = 39 dims, 2,000 tied states x 16 diagonal Gaussians), i.e.
+   samples -> MFCC -> smoothing + deltas -> dense GMM log-likelihoods [T x 2000] -> Viterbi alignment.
+Inputs are resident in HBM before the timed region.  With N > 1 every rank owns its own 1,000
+utterances (weak scaling, no data-path collective: utterances are independent).
+
+Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel (GMM scoring, f32 MFMA) timed
+with events on the launch stream; `cpu_baseline` times the CPU oracle (a port of the reference's
+arithmetic, test infrastructure) on a bounded sample of the same workload on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WL, HOP, NCEPS, NFILT, FEND, SPS = 400, 160, 13, 48, 7200.0, 16000
+G, M, D = 2000, 16, 39
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def build_workload(n_utt, seed):
+    from speechrecognition_amd import host, synth
+    x, soff = synth.corpus_audio(n_utt, seed)
+    rng = np.random.default_rng(seed + 99)
+    ntrs, trs, tieds = [], [], []
+    for _ in range(n_utt):
+        ph = synth.phone_string(rng)
+        ntr, tr, _ = host.build_training_hmm(ph)
+        ntrs.append(ntr)
+        trs.append(tr)
+        tieds.append(rng.integers(0, G, len(ph)).astype(np.int32))
+    return x, soff, ntrs, trs, tieds
+
+
+def cpu_baseline(x, soff, ntrs, trs, tieds, model, budget_s=20.0):
+    """Times the oracle (kind "port") end to end on a bounded sample of the same utterances."""
+    from oracle import oracle as O
+    O.build()
+    mean, var, w = model
+    lw = O.set_wt(w)
+    fb, _ = O.mel_filterbank(FEND, NFILT, WL, SPS)
+    mean_l = np.ascontiguousarray(mean, np.longdouble)
+    var_l = np.ascontiguousarray(var, np.longdouble)
+    threads = int(min(16, os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    # calibrate on one short utterance, single thread
+    order = np.argsort(np.diff(soff))
+    u0 = int(order[0])
+    t0 = time.perf_counter()
+    n0, _, _ = O.pipeline_utterance(x[soff[u0]:soff[u0 + 1]], WL, HOP, fb, NCEPS, 0.96, 2, mean_l, var_l, lw, D, 1,
+                                    tieds[u0], ntrs[u0], trs[u0])
+    dt0 = time.perf_counter() - t0
+    per_frame_state = dt0 / (n0 * len(ntrs[u0]))
+    # pick utterances (shortest first) until ~budget_s of wall time across the thread pool
+    chosen, est = [], 0.0
+    for u in order[1:]:
+        u = int(u)
+        cost = per_frame_state * ((soff[u + 1] - soff[u]) / HOP) * len(ntrs[u])
+        if chosen and (est + cost) / threads > budget_s:
+            break
+        chosen.append(u)
+        est += cost
+        if len(chosen) >= 4 * threads:
+            break
+    frames = [0] * len(chosen)
+
+    def work(k0):
+        for k in range(k0, len(chosen), threads):
+            u = chosen[k]
+            n, _, _ = O.pipeline_utterance(x[soff[u]:soff[u + 1]], WL, HOP, fb, NCEPS, 0.96, 2, mean_l, var_l, lw, D, 1,
+                                           tieds[u], ntrs[u], trs[u])
+            frames[k] = n
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    return {
+        "value": sum(frames) / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+        "sample": f"{len(chosen)} shortest of the 1000 utterances ({sum(frames)} frames) in {dt:.1f} s; oracle/srx_oracle.c "
+                  f"(naive half-window DFT in f64, long-double Gaussians of the utterance's own states only, "
+                  f"accumulating Viterbi); single-thread calibration {n0 / dt0:.0f} frames/s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--utts", type=int, default=1000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(local)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    from speechrecognition_amd import SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA, host, synth
+    stream = torch.cuda.current_stream()
+    ctx = host.Context(local, stream.cuda_stream)
+
+    # ---- workload, resident in HBM ----
+    x, soff, ntrs, trs, tieds = build_workload(args.utts, seed=1 + rank)
+    fb, _ = host.mel_filterbank(FEND, NFILT, WL, SPS)
+    cfg = host.mfcc_config(WL, HOP, NCEPS)
+    plan = host.MfccPlan(ctx, cfg, fb)
+    foff = host.frame_offsets(cfg, soff)
+    T = int(foff[-1])
+    n_utt = args.utts
+    model_np = synth.random_model(G, M, D, 777)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(*model_np)
+    hb = host.HmmBatch(ctx, foff, ntrs, trs, tieds)
+    x_d, soff_d = ctx.array(x), ctx.array(soff)
+    scale_d = ctx.empty((n_utt,), np.float32)
+    ceps_d = ctx.empty((T, NCEPS), np.float32)
+    feats_d = ctx.empty((T, 3 * NCEPS), np.float32)
+    emis_d = ctx.empty((T, G), np.float32)
+    path_d = ctx.zeros((T,), np.int32)
+    final_d = ctx.zeros((n_utt,), np.float32)
+    status_d = ctx.zeros((n_utt,), np.int32)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stage_ms = {"mfcc": 0.0, "features": 0.0, "gmm": 0.0, "viterbi": 0.0}
+
+    def step(timed):
+        e = [ev() for _ in range(5)] if timed else None
+        if timed: e[0].record(stream)
+        plan.write_features_dev(x_d, soff_d, n_utt, hb.frame_off_d, T, scale_d, ceps_d)
+        if timed: e[1].record(stream)
+        host.read_features_dev(ctx, 2, NCEPS, ceps_d, hb.frame_off_d, n_utt, T, feats_d)
+        if timed: e[2].record(stream)
+        model.score_dev(feats_d, 3 * NCEPS, T, emis_d, G, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA)
+        if timed: e[3].record(stream)
+        hb.viterbi(emis_d, G, 1e10, path_d, final_d, status_d)
+        if timed: e[4].record(stream)
+        return e
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    evs = [step(True) for _ in range(args.steps)]
+    barrier()
+    dt = time.perf_counter() - t0
+    for e in evs:
+        for k, name in enumerate(("mfcc", "features", "gmm", "viterbi")):
+            stage_ms[name] += e[k].elapsed_time(e[k + 1]) / args.steps
+
+    status = status_d.get()
+    assert (status == 0).all(), "alignment failed for some utterance"
+
+    tot = torch.tensor([dt, float(T)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max, frames_all = float(tmax[0]), float(tot[1])
+    else:
+        dt_max, frames_all = dt, float(T)
+
+    if rank == 0:
+        ms_step = dt_max / args.steps * 1e3
+        flop_per_frame = 2.0 * (2 * D + 1) * G * M          # GMM scoring, all states
+        gmm_tflops = flop_per_frame * T / (stage_ms["gmm"] * 1e-3) / 1e12
+        mfcc_bytes = (HOP * 4 + NCEPS * 4) * T               # 692 B/frame
+        vit_S = float(np.mean([len(n) for n in ntrs]))
+        vit_bytes = (4.25 * vit_S + 5) * T
+        out = {
+            "metric": "audio frames/sec (node) through MFCC+GMM+Viterbi",
+            "value": frames_all * args.steps / dt_max, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1] corpus: 1000 synthetic Voxforge-shaped utterances (2-8 s, 16 kHz) per GPU -> "
+                                   "MFCC 25ms/10ms, 48 mel filters, 13 ceps -> smoothing+deltas (39 dims) -> dense GMM "
+                                   "scoring 2000 tied states x 16 diag Gaussians x 39 dims (log-sum-exp) -> Viterbi forced "
+                                   "alignment of every utterance",
+                       "utterances_per_gpu": n_utt, "frames_per_gpu": T, "window": WL, "hop": HOP, "G": G, "M": M, "D": D,
+                       "mean_states_per_utt": vit_S, "parallelism": f"utterance-sharded x{world}"},
+            "roofline": {"bound": "mfma", "achieved": gmm_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gmm_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "k_gmm_mfma<16,4>", "flop_per_frame": flop_per_frame, "ms_per_launch": stage_ms["gmm"]},
+            "stages_ms": stage_ms,
+            "stage_rooflines": {
+                "mfcc_hbm": {"achieved_GBs": mfcc_bytes / (stage_ms["mfcc"] * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                             "frac": mfcc_bytes / (stage_ms["mfcc"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_frame": 692},
+                "viterbi_hbm": {"achieved_GBs": vit_bytes / (stage_ms["viterbi"] * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,
+                                "frac": vit_bytes / (stage_ms["viterbi"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "bytes_per_frame": 4.25 * vit_S + 5},
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(x, soff, ntrs, trs, tieds, model_np)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,7 @@ typedef struct {
     const int32_t *ntr_dev;       /* [n_states] 1..3 */
     float *trlogp_dev;            /* [n_states][3] (mutated by srx_train_transitions_dev) */
     int max_states;               /* max over utterances of S (host-known; <= 256) */
+    int64_t total_frames;         /* frame_off[n_utt] (host-known) */
 } srx_hmm_batch;
 
 /* hmm::viterbi  src/hmm.cpp:150-224 for every utterance of the batch, emission scores given:
@@ -189,20 +190,20 @@ int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int3
  * points where ranks must exchange sums.  A = model the statistics are taken
  * under (hmm::acm), B = model rebuilt (hmm::temp_acm).  gid[t] = tied state of aligned frame t
  * (-1: frame skipped, e.g. NO PATH utterance).
- *   1. srx_em_shift_dev      per-state max log-density  -> shift[G]      (all-reduce MAX)
+ *   1. srx_em_shift_dev      per-component max log-density -> shift[G*M] (all-reduce MAX)
  *   2. srx_em_pass1_dev      zeta sums and zeta*x sums  -> stats1[G*M*(1+D)] f64 (all-reduce SUM)
  *   3. srx_em_means_dev      weights + means of B from stats1
  *   4. srx_em_pass2_dev      zeta*(x-mean_B)^2 sums     -> stats2[G*M*D] f64     (all-reduce SUM)
  *   5. srx_em_finish_dev     variances of B, then B = keep*B + (1-keep)*A (gaussian::blend)
- * zeta is computed as w*exp(logp - shift[g]) in f64 (the reference uses unshifted 80-bit values;
- * every quantity it derives from them is a ratio that the shift cancels). */
+ * zeta is computed as w*exp(logp - shift[g][m]) in f64 (the reference uses unshifted 80-bit values;
+ * every quantity it derives from them is a ratio in which the shift cancels or is re-applied). */
 int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,
                           const int32_t *status_dev, int64_t total_frames, int32_t *gid_dev);
 int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
-                     float *logp_dev /*[T][M] out*/, float *shift_dev /*[G] out*/);
+                     float *logp_dev /*[T][M] out*/, float *shift_dev /*[G*M] out*/);
 int srx_em_pass1_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
                      const float *logp_dev, const float *shift_dev, double *stats1_dev);
-int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1_dev);
+int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1_dev, const float *shift_dev);
 int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const float *feats_dev, int ld,
                      const int32_t *gid_dev, int64_t T, const float *logp_dev, const float *shift_dev,
                      double *stats2_dev);

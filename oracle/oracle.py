@@ -55,6 +55,7 @@ def lib():
         L.orc_gaussian_logprob.restype = C.c_float
         L.orc_gaussian_logprob.argtypes = [f32p, ldp, ldp, C.c_float, C.c_int]
         L.orc_gmm_score.argtypes = [f32p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, ldp, ldp, f32p, C.c_int, f32p]
+        L.orc_set_wt.argtypes = [f32p, f32p, C.c_long]
         L.orc_build_training_hmm.argtypes = [i32p, C.c_int, i32p, f32p, i32p]
         L.orc_viterbi.restype = C.c_int
         L.orc_viterbi.argtypes = [f32p, C.c_long, C.c_void_p, C.c_long, C.c_int, i32p, f32p, C.c_float, C.c_int,
@@ -128,6 +129,14 @@ def corpus_mean_var(feats, D):
 
 
 # ---------------------------------------------------------------- GMM
+def set_wt(w):
+    """logwt = logf(weight), gaussian::set_wt src/gmm.cpp:35-38 (glibc logf)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    lw = np.zeros_like(w)
+    lib().orc_set_wt(w.reshape(-1), lw.reshape(-1), w.size)
+    return lw
+
+
 def gmm_score(feats, mean, var, logwt, D, mode=0):
     """feats [T, ld] f32; mean/var [G, M, D] (any float dtype, used as long double);
     logwt [G, M] f32 -> [T, G] f32."""
@@ -186,7 +195,7 @@ def em_statistics(feats, gid, D, A_mean, A_var, A_weight, blend_keep=0.2):
     A_mean = np.ascontiguousarray(A_mean, dtype=np.longdouble)
     A_var = np.ascontiguousarray(A_var, dtype=np.longdouble)
     A_weight = np.ascontiguousarray(A_weight, dtype=np.float32)
-    A_logwt = np.log(A_weight).astype(np.float32)  # logf(w): set_wt, src/gmm.cpp:35-38
+    A_logwt = set_wt(A_weight)
     G, M, _ = A_mean.shape
     B_mean = np.zeros_like(A_mean)
     B_var = np.zeros_like(A_var)

@@ -263,6 +263,11 @@ float orc_gaussian_logprob(const float *fv, const long double *mean, const long 
     return -0.5f * res + logwt;
 }
 
+/* gaussian::set_wt  src/gmm.cpp:35-38: logwt = log(wt) on a float -> logf */
+void orc_set_wt(const float *w, float *lw, long n) {
+    for (long i = 0; i < n; i++) lw[i] = logf(w[i]);
+}
+
 /* acoustic_model::operator() over all tied states: out[t][g].
  * mode 0: gmm::operator() as written (component 0 only)  src/gmm.cpp:99-100
  * mode 1: the commented-out intent log(sum_m exp(g_m)) in double  src/gmm.cpp:103-107 */

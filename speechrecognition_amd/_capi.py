@@ -36,7 +36,7 @@ class srx_mfcc_cfg(C.Structure):
 
 class srx_hmm_batch(C.Structure):
     _fields_ = [("n_utt", C.c_int), ("frame_off_dev", C.c_void_p), ("state_off_dev", C.c_void_p),
-                ("tied_dev", C.c_void_p), ("ntr_dev", C.c_void_p), ("trlogp_dev", C.c_void_p), ("max_states", C.c_int)]
+                ("tied_dev", C.c_void_p), ("ntr_dev", C.c_void_p), ("trlogp_dev", C.c_void_p), ("max_states", C.c_int), ("total_frames", C.c_int64)]
 
 
 vp = C.c_void_p
@@ -79,7 +79,7 @@ SIGNATURES = {
     "srx_em_gather_gid_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, i64, vp]),
     "srx_em_shift_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, i64, vp, vp]),
     "srx_em_pass1_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, i64, vp, vp, vp]),
-    "srx_em_means_dev": (C.c_int, [vp, vp, vp]),
+    "srx_em_means_dev": (C.c_int, [vp, vp, vp, vp]),
     "srx_em_pass2_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp, vp]),
     "srx_em_finish_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_float]),
 }

@@ -55,11 +55,6 @@ extern "C" void srx_model_destroy(srx_model *m) {
     delete m;
 }
 
-__global__ void k_logwt(const float *__restrict__ w, float *__restrict__ lw, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) lw[i] = logf(w[i]);  // gaussian::set_wt  src/gmm.cpp:35-38
-}
-
 extern "C" int srx_model_set(srx_model *m, const double *mean, const double *var, const float *weight) {
     SRX_REQUIRE(nullptr, m, "srx_model_set: null model");
     srx_ctx *ctx = m->ctx;
@@ -68,8 +63,10 @@ extern "C" int srx_model_set(srx_model *m, const double *mean, const double *var
     SRX_HIP(ctx, hipMemcpyAsync(m->mean, mean, n * m->D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     SRX_HIP(ctx, hipMemcpyAsync(m->var, var, n * m->D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     SRX_HIP(ctx, hipMemcpyAsync(m->weight, weight, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_logwt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m->weight, m->logwt, (int)n);
-    SRX_LAUNCH_CHECK(ctx);
+    // gaussian::set_wt (src/gmm.cpp:35-38): logwt = log(wt) in f32, on the host like the reference
+    std::vector<float> lw(n);
+    for (size_t i = 0; i < n; i++) lw[i] = logf(weight[i]);
+    SRX_HIP(ctx, hipMemcpyAsync(m->logwt, lw.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m->dirty = true;
     return SRX_OK;

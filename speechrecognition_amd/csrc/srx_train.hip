@@ -6,9 +6,10 @@
 // re-evaluates gaussian::prob three times per aligned frame; here the per-frame log-densities are
 // evaluated once (in the reference's operation order, f64 for long double), kept, and the three
 // accumulations run frame-parallel with f64 atomics -- LDS-privatised per workgroup when the table
-// fits, straight to HBM otherwise.  zeta = w * exp(logp - shift[g]) with shift[g] the largest
-// log-density seen for tied state g: every statistic the reference derives is a ratio of zeta sums of
-// one state, so the shift cancels while keeping exp() inside f64 range.
+// fits, straight to HBM otherwise.  zeta = w * exp(logp - shift[g][m]) with shift[g][m] the largest
+// log-density component (g,m) saw: means and variances are ratios of one component's zeta sums, so the
+// shift cancels; the mixture weights re-apply exp(shift[g][m] - max_m shift[g][m]) before normalising.
+// This keeps exp() inside f64 range where the reference relies on the 80-bit exponent.
 #include <cmath>
 
 #include "srx_common.h"
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void k_em_logp(const float *__restrict__ feats
     const size_t o = (size_t)g * M + m;
     const float lp = logprob_exact(feats + t * ld, mean + o * D, var + o * D, logwt[o], D);
     logp[idx] = lp;
-    if (lp == lp) atomic_max_float(&shift[g], lp);
+    if (lp == lp) atomic_max_float(&shift[o], lp);
 }
 
 // Accumulation.  PASS 1: row o = [zeta, zeta*x_0 .. zeta*x_{D-1}] (stride 1+D).
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_em_accum(const float *__restrict__ feat
         if (g < 0) continue;
         const size_t o = (size_t)g * M + m;
         // zeta = weight * prob  (src/hmm.cpp:282,307,328), shifted
-        const double zeta = (double)weight[o] * exp((double)logp[idx] - (double)shift[g]);
+        const double zeta = (double)weight[o] * exp((double)logp[idx] - (double)shift[o]);
         const float *fv = feats + t * ld;
         double *row = dst + o * stride;
         if (PASS == 1) {
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void k_em_accum(const float *__restrict__ feat
 }
 
 // weights and means of B from stats1  (src/hmm.cpp:288-296, 317; gaussian::clear sets var = 0)
-__global__ __launch_bounds__(256) void k_em_means(int G, int M, int D, const double *__restrict__ stats1, double *__restrict__ meanB,
+__global__ __launch_bounds__(256) void k_em_means(int G, int M, int D, const double *__restrict__ stats1,
+                                                  const float *__restrict__ shift, double *__restrict__ meanB,
                                                   double *__restrict__ varB, float *__restrict__ wB, float *__restrict__ lwB) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)G * M * D) return;
@@ -126,9 +128,18 @@ __global__ __launch_bounds__(256) void k_em_means(int G, int M, int D, const dou
     meanB[idx] = stats1[o * (1 + D) + 1 + e] / zs;
     varB[idx] = 0.0;
     if (e == 0) {
-        double zg = 0.0;
-        for (int m = 0; m < M; m++) zg += stats1[((size_t)g * M + m) * (1 + D)];
-        const float w = (float)(zs / zg);
+        // zetasum[o] = stats1[o][0] * exp(shift[o]); normalise within the state (src/hmm.cpp:291-295)
+        float smax = -__builtin_huge_valf();
+        for (int m = 0; m < M; m++) smax = fmaxf(smax, shift[(size_t)g * M + m]);
+        double zg = 0.0, zo = 0.0;
+        for (int m = 0; m < M; m++) {
+            const size_t om = (size_t)g * M + m;
+            const float sh = shift[om];
+            const double z = (sh == -__builtin_huge_valf()) ? 0.0 : stats1[om * (1 + D)] * exp((double)sh - (double)smax);
+            zg += z;
+            if (om == o) zo = z;
+        }
+        const float w = (float)(zo / zg);
         wB[o] = w;
         lwB[o] = logf(w);
     }
@@ -173,7 +184,8 @@ extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
                                 float *logp_dev, float *shift_dev) {
     SRX_REQUIRE(nullptr, ctx, "srx_em_shift_dev: null ctx");
     SRX_REQUIRE(ctx, A && feats_dev && gid_dev && logp_dev && shift_dev && T >= 0 && ld >= A->D, "srx_em_shift_dev: bad argument");
-    hipLaunchKernelGGL(k_fill_f32, dim3((A->G + 255) / 256), dim3(256), 0, ctx->stream, shift_dev, -__builtin_huge_valf(), A->G);
+    hipLaunchKernelGGL(k_fill_f32, dim3((A->G * A->M + 255) / 256), dim3(256), 0, ctx->stream, shift_dev, -__builtin_huge_valf(),
+                       A->G * A->M);
     SRX_LAUNCH_CHECK(ctx);
     if (T == 0) return SRX_OK;
     const int64_t n = T * A->M;
@@ -216,12 +228,12 @@ extern "C" int srx_em_pass1_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
     return launch_accum<1>(ctx, A, nullptr, feats_dev, ld, gid_dev, T, logp_dev, shift_dev, stats1_dev);
 }
 
-extern "C" int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1_dev) {
+extern "C" int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1_dev, const float *shift_dev) {
     SRX_REQUIRE(nullptr, ctx, "srx_em_means_dev: null ctx");
-    SRX_REQUIRE(ctx, B && stats1_dev, "srx_em_means_dev: null argument");
+    SRX_REQUIRE(ctx, B && stats1_dev && shift_dev, "srx_em_means_dev: null argument");
     const int64_t n = (int64_t)B->G * B->M * B->D;
-    hipLaunchKernelGGL(k_em_means, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev, B->mean,
-                       B->var, B->weight, B->logwt);
+    hipLaunchKernelGGL(k_em_means, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev, shift_dev,
+                       B->mean, B->var, B->weight, B->logwt);
     SRX_LAUNCH_CHECK(ctx);
     B->dirty = true;
     return SRX_OK;

@@ -309,10 +309,8 @@ extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
     SRX_REQUIRE(ctx, hmm->n_utt >= 0 && hmm->max_states >= 1 && hmm->max_states <= 256,
                 "srx_viterbi_batch_dev: max_states %d outside 1..256", hmm->max_states);
     if (hmm->n_utt == 0) return SRX_OK;
-    // total frames is needed to size the back-pointer workspace: read frame_off[n_utt]
-    int64_t total_frames = 0;
-    SRX_HIP(ctx, hipMemcpyAsync(&total_frames, hmm->frame_off_dev + hmm->n_utt, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t total_frames = hmm->total_frames;
+    SRX_REQUIRE(ctx, total_frames >= 0, "srx_viterbi_batch_dev: negative total_frames");
     const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : 4);
     const size_t words = ((size_t)(total_frames >> 4) + (size_t)hmm->n_utt + 1) * 64 * spl;
     void *ws = nullptr;

@@ -270,7 +270,7 @@ class HmmBatch:
         self.trlogp_d = ctx.array(np.concatenate(trlogp_list).astype(np.float32).reshape(-1, 3))
         self.total_frames = int(self.frame_off[-1])
         self.c = srx_hmm_batch(self.n_utt, self.frame_off_d.ptr, self.state_off_d.ptr, self.tied_d.ptr, self.ntr_d.ptr,
-                               self.trlogp_d.ptr, self.max_states)
+                               self.trlogp_d.ptr, self.max_states, self.total_frames)
 
     def trlogp(self):
         return self.trlogp_d.get()
@@ -297,7 +297,7 @@ def em_statistics(ctx, A, B, feats_d, ld, gid_d, T, blend_keep=0.2, allreduce_ma
     lib = ctx.lib
     G, M, D = A.G, A.M, A.D
     logp = ctx.empty((max(T * M, 1),), np.float32)
-    shift = ctx.empty((G,), np.float32)
+    shift = ctx.empty((G * M,), np.float32)
     stats1 = ctx.empty((G * M * (1 + D),), np.float64)
     stats2 = ctx.empty((G * M * D,), np.float64)
     check(lib.srx_em_shift_dev(ctx.h, A.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr, shift.ptr), ctx.h)
@@ -306,7 +306,7 @@ def em_statistics(ctx, A, B, feats_d, ld, gid_d, T, blend_keep=0.2, allreduce_ma
     check(lib.srx_em_pass1_dev(ctx.h, A.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr, shift.ptr, stats1.ptr), ctx.h)
     if allreduce_sum:
         allreduce_sum(stats1)
-    check(lib.srx_em_means_dev(ctx.h, B.h, stats1.ptr), ctx.h)
+    check(lib.srx_em_means_dev(ctx.h, B.h, stats1.ptr, shift.ptr), ctx.h)
     check(lib.srx_em_pass2_dev(ctx.h, A.h, B.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr, shift.ptr, stats2.ptr), ctx.h)
     if allreduce_sum:
         allreduce_sum(stats2)
