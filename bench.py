@@ -75,7 +75,7 @@ def cpu_baseline(x, soff, ntrs, trs, tieds, model, budget_s=20.0):
             break
         chosen.append(u)
         est += cost
-        if len(chosen) >= 4 * threads:
+        if len(chosen) >= 40 * threads:
             break
     frames = [0] * len(chosen)
 
@@ -123,7 +123,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from speechrecognition_amd import SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA, host, synth
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()   # a real (non-null) stream: libsrx launches on it and the events below time it
+    torch.cuda.set_stream(stream)
     ctx = host.Context(local, stream.cuda_stream)
 
     # ---- workload, resident in HBM ----
