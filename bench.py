@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--frame-major", action="store_true", help="emission matrix as [T][G] instead of [G][T]")
     args = ap.parse_args()
 
     import torch
@@ -144,6 +145,8 @@ def main():
     ceps_d = ctx.empty((T, NCEPS), np.float32)
     feats_d = ctx.empty((T, 3 * NCEPS), np.float32)
     emis_d = ctx.empty((T, G), np.float32)
+    # emission matrix layout: state-major [G][T] (default) or frame-major [T][G]
+    ST_T, ST_G = (G, 1) if args.frame_major else (1, T)
     path_d = ctx.zeros((T,), np.int32)
     final_d = ctx.zeros((n_utt,), np.float32)
     status_d = ctx.zeros((n_utt,), np.int32)
@@ -158,9 +161,9 @@ def main():
         if timed: e[1].record(stream)
         host.read_features_dev(ctx, 2, NCEPS, ceps_d, hb.frame_off_d, n_utt, T, feats_d)
         if timed: e[2].record(stream)
-        model.score_dev(feats_d, 3 * NCEPS, T, emis_d, G, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA)
+        model.score_dev(feats_d, 3 * NCEPS, T, emis_d, ST_T, ST_G, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA)
         if timed: e[3].record(stream)
-        hb.viterbi(emis_d, G, 1e10, path_d, final_d, status_d)
+        hb.viterbi(emis_d, ST_T, ST_G, 1e10, path_d, final_d, status_d)
         if timed: e[4].record(stream)
         return e
 

@@ -145,9 +145,11 @@ typedef enum {
 } srx_score_path;
 
 /* acoustic_model::operator()(fv, ctx) for every frame and every tied state
- * (src/gmm.cpp:41-49, 99-109, 184-186): out[t][g], ld_out >= G. */
+ * (src/gmm.cpp:41-49, 99-109, 184-186).  Score (t, g) is written to out[t*stride_t + g*stride_g]:
+ * frame-major (stride_g = 1, stride_t >= G) or state-major (stride_t = 1, stride_g >= T; the layout
+ * the Viterbi kernel streams best). */
 int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
-                      int64_t T, float *out_dev, int64_t ld_out);
+                      int64_t T, float *out_dev, int64_t stride_t, int64_t stride_g);
 int srx_gmm_score(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats, int ld, int64_t T,
                   float *out);
 
@@ -170,15 +172,16 @@ typedef struct {
 } srx_hmm_batch;
 
 /* hmm::viterbi  src/hmm.cpp:150-224 for every utterance of the batch, emission scores given:
- * emis[t*ld_emis + tied[s]] = (*acm)(*fvs[t], states[s].ctx).  Outputs: path[total_frames]
+ * emis[t*stride_t + tied[s]*stride_g] = (*acm)(*fvs[t], states[s].ctx), t counted over the whole
+ * batch (the strides of srx_gmm_score_dev).  Outputs: path[total_frames]
  * (state index within the utterance), final_logp[n_utt] (= curr[best]), status[n_utt]
  * (0 ok, 1 "NO PATH": path/final untouched).  prevp of the reference = final_logp / T.
  * Score is bit-exact w.r.t. the reference's f32 add order (it accumulates logp across a source's
  * transitions, src/hmm.cpp:164-169); exact ties are resolved towards the higher source index
  * (the reference's order is unordered_map iteration order, i.e. unspecified).
  * beam_width >= 1e10 (the reference default, src/hmm.cpp:150) disables the beam test. */
-int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t ld_emis,
-                          float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
+int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
+                          int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
 
 /* hmm::train_transition_probabilities  src/hmm.cpp:229-243 (+ set/get_adv_prob :26-35) for every
  * utterance whose status is 0. */

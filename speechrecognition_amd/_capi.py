@@ -71,10 +71,10 @@ SIGNATURES = {
     "srx_model_set": (C.c_int, [vp, vp, vp, vp]),
     "srx_model_get": (C.c_int, [vp, vp, vp, vp]),
     "srx_model_copy": (C.c_int, [vp, vp]),
-    "srx_gmm_score_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp, i64]),
+    "srx_gmm_score_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp, i64, i64]),
     "srx_gmm_score": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp]),
     "srx_hmm_build_training": (C.c_int, [vp, C.c_int, vp, vp, vp]),
-    "srx_viterbi_batch_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, i64, C.c_float, vp, vp, vp]),
+    "srx_viterbi_batch_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, i64, i64, C.c_float, vp, vp, vp]),
     "srx_train_transitions_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp]),
     "srx_em_gather_gid_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, i64, vp]),
     "srx_em_shift_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, i64, vp, vp]),

@@ -116,7 +116,7 @@ __device__ __forceinline__ float gaussian_logprob_exact(const float *__restrict_
 __global__ __launch_bounds__(256) void k_gmm_exact(const float *__restrict__ feats, int ld, int64_t T, int G, int M, int D,
                                                    const double *__restrict__ mean, const double *__restrict__ var,
                                                    const float *__restrict__ logwt, int mode, float *__restrict__ out,
-                                                   int64_t ldo) {
+                                                   int64_t st_t, int64_t st_g) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T * G) return;
     const int64_t t = idx / G;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float *__restrict__ fea
         }
         r = (float)log(s);
     }
-    out[t * ldo + g] = r;
+    out[t * st_t + (int64_t)g * st_g] = r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -231,66 +231,132 @@ static int ensure_packed(srx_ctx *ctx, srx_model *m, int mix_mode) {
 }
 
 // ------------------------------------------------------------------------------------------
-// MFMA path: scoring kernel.  Workgroup = 4 waves; block tile = RT row tiles (32 Gaussians each)
-// x 128 frames; wave w owns frames 32w..32w+31 and all RT row tiles.
+// MFMA path: scoring kernel.  Workgroup = 4 waves sharing one parameter tile of RT row tiles
+// (32 Gaussians each) in LDS; every wave walks its own sequence of 32-frame tiles (no workgroup
+// barrier inside the loop, so the waves of a SIMD drift apart and one's epilogue/stores overlap
+// the other's MFMAs).  out element (t, g) lives at out[t*st_t + g*st_g]: st_t == 1 (state-major)
+// makes every store 128 contiguous bytes per half-wave.
 // ------------------------------------------------------------------------------------------
-static constexpr int FT = 128;       // frames per block tile
-static constexpr int XLD = FT + 1;   // xs row stride (odd: transposing stores spread over banks)
+static constexpr int WF = 32;        // frames per wave tile (MFMA columns)
+static constexpr int NXR = 20;       // staging registers per lane: covers WF*D <= 1280 (D <= 40) in one batch
 
-template <int MP, int RT>
+// Copies this wave's WF frames (rows of D floats, row stride ld) into its LDS slab xs[frame][DP]
+// through registers.  `load` issues the global loads (so they can fly during the MFMA loop of the
+// previous tile), `store` writes them to LDS.  Rows past T read as zero.
+template <bool CONTIG>
+__device__ __forceinline__ void stage_load(float (&rx)[NXR], const float *__restrict__ feats, int ld, int64_t T, int64_t t0, int D,
+                                           int lane, int batch) {
+    const int nel = WF * D;
+    const int64_t lim = (T - t0) * (int64_t)D;  // elements that exist (contiguous case)
+#pragma unroll
+    for (int i = 0; i < NXR; i++) {
+        const int idx = batch * (NXR * 64) + i * 64 + lane;
+        float v = 0.0f;
+        if (CONTIG) {
+            if (idx < nel && idx < lim) v = feats[t0 * ld + idx];
+        } else {
+            const int t = idx / D, d = idx - t * D;
+            if (idx < nel && t0 + t < T) v = feats[(t0 + t) * ld + d];
+        }
+        rx[i] = v;
+    }
+}
+template <bool CONTIG>
+__device__ __forceinline__ void stage_store(const float (&rx)[NXR], float *xs, int D, int DP, int lane, int batch) {
+    const int nel = WF * D;
+#pragma unroll
+    for (int i = 0; i < NXR; i++) {
+        const int idx = batch * (NXR * 64) + i * 64 + lane;
+        if (idx < nel) {
+            if (CONTIG && DP == D) {
+                xs[idx] = rx[i];
+            } else {
+                const int t = idx / D, d = idx - t * D;
+                xs[t * DP + d] = rx[i];
+            }
+        }
+    }
+}
+
+template <int MP, int RT, bool CONTIG>
 __global__ __launch_bounds__(256, 2) void k_gmm_mfma(const float *__restrict__ feats, int ld, int64_t T,
                                                      const float *__restrict__ center, const float *__restrict__ packed, int D,
-                                                     int G, float *__restrict__ out, int64_t ldo) {
+                                                     int DP, int G, float *__restrict__ out, int64_t st_t, int64_t st_g) {
     extern __shared__ float lds[];
     const int KS = D + 1;
-    float *Pl = lds;                      // [RT][KS][64]
-    float *xs = lds + RT * KS * 64;       // [D][XLD]
+    float *Pl = lds;                                   // [RT][KS][64]
+    float *cl = lds + RT * KS * 64;                    // [D] centring vector
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float *xs = cl + ((D + 3) & ~3) + w * (WF * DP);   // this wave's [WF][DP] (DP odd: conflict-free column reads)
     const int j = lane & 31, h = lane >> 5;
 
-    // parameter tile: contiguous in the packed array
     {
         const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)blockIdx.y * RT * KS * 64);
         float4 *dst = reinterpret_cast<float4 *>(Pl);
         const int n4 = RT * KS * 16;
         for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+        for (int i = tid; i < D; i += 256) cl[i] = center[i];
     }
-    const int64_t nft = (T + FT - 1) / FT;
+    __syncthreads();
+    const int64_t nwt = (T + WF - 1) / WF;
     constexpr int NST = 16 / MP;          // states per lane half per row tile
     constexpr int SPT = 32 / MP;          // states per row tile
-    for (int64_t ft = blockIdx.x; ft < nft; ft += gridDim.x) {
-        __syncthreads();
-        const int64_t t0 = ft * FT;
-        for (int idx = tid; idx < FT * D; idx += 256) {
-            const int t = idx / D, d = idx - t * D;
-            const int64_t fr = t0 + t;
-            float v = 0.0f;
-            if (fr < T) v = feats[fr * ld + d] - center[d];
-            xs[d * XLD + t] = v;
+    const float *pl = Pl + lane;
+    const float *xrow = xs + j * DP;
+    const int nbatch = (WF * D + NXR * 64 - 1) / (NXR * 64);
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    int64_t wt = (int64_t)blockIdx.x * 4 + w;
+    float rx[NXR];
+    if (wt < nwt) stage_load<CONTIG>(rx, feats, ld, T, wt * WF, D, lane, 0);
+    for (; wt < nwt; wt += wstride) {
+        const int64_t t0 = wt * WF;
+        // ---- finish staging tile wt (batch 0 is already in registers) ----
+        stage_store<CONTIG>(rx, xs, D, DP, lane, 0);
+        for (int bt = 1; bt < nbatch; bt++) {
+            stage_load<CONTIG>(rx, feats, ld, T, t0, D, lane, bt);
+            stage_store<CONTIG>(rx, xs, D, DP, lane, bt);
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        // ---- prefetch the next tile's first batch; it lands while the MFMAs run ----
+        if (wt + wstride < nwt) stage_load<CONTIG>(rx, feats, ld, T, (wt + wstride) * WF, D, lane, 0);
+
         f32x16 acc[RT];
 #pragma unroll
         for (int r = 0; r < RT; r++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[r][e] = 0.0f;
-        const float *xcol = xs + 32 * w + j;
-        const float *pl = Pl + lane;
+        // software-pipelined k loop: operands of step s+1 are read while step s multiplies
+        float an[RT], xn, cn;
+#pragma unroll
+        for (int r = 0; r < RT; r++) an[r] = pl[(r * KS) * 64];
+        xn = xrow[0];
+        cn = cl[0];
         for (int s = 0; s < D; s++) {
-            const float xv = xcol[s * XLD];
+            float ac[RT];
+#pragma unroll
+            for (int r = 0; r < RT; r++) ac[r] = an[r];
+            const float xv = xn - cn;
+            const int sn = s + 1;
+#pragma unroll
+            for (int r = 0; r < RT; r++) an[r] = pl[(r * KS + sn) * 64];
+            if (sn < D) {
+                xn = xrow[sn];
+                cn = cl[sn];
+            }
             const float b = h ? xv : xv * xv;
 #pragma unroll
-            for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(pl[(r * KS + s) * 64], b, acc[r], 0, 0, 0);
+            for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[r], b, acc[r], 0, 0, 0);
         }
         {
             const float b = h ? 0.0f : 1.0f;
 #pragma unroll
-            for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(pl[(r * KS + D) * 64], b, acc[r], 0, 0, 0);
+            for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[r], b, acc[r], 0, 0, 0);
         }
-        // epilogue: per-state log-sum-exp over the lane's registers, then store
-        const int64_t fr = t0 + 32 * w + j;
+        __builtin_amdgcn_wave_barrier();
+        // ---- epilogue: per-state log-sum-exp over the lane's registers, then store ----
+        const int64_t fr = t0 + j;
         if (fr < T) {
-            float *orow = out + fr * ldo;
+            float *orow = out + fr * st_t;
 #pragma unroll
             for (int r = 0; r < RT; r++) {
                 const int gbase = ((int)blockIdx.y * RT + r) * SPT + h * NST;
@@ -309,57 +375,68 @@ __global__ __launch_bounds__(256, 2) void k_gmm_mfma(const float *__restrict__ f
                         v = mx + __logf(sum);
                     }
                     const int g = gbase + st;
-                    if (g < G) orow[g] = v;
+                    if (g < G) orow[(int64_t)g * st_g] = v;
                 }
             }
         }
     }
 }
 
-template <int MP, int RT>
-static int launch_mfma(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t ldo) {
+template <int MP, int RT, bool CONTIG>
+static int launch_mfma2(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t st_t, int64_t st_g) {
     const int KS = m->D + 1;
-    const size_t lds_bytes = ((size_t)RT * KS * 64 + (size_t)m->D * XLD) * sizeof(float);
+    const int DP = m->D | 1;  // odd row stride
+    const size_t lds_bytes = ((size_t)RT * KS * 64 + ((m->D + 3) & ~3) + (size_t)4 * WF * DP) * sizeof(float);
     SRX_REQUIRE(ctx, lds_bytes <= 160 * 1024, "srx_gmm_score: D=%d needs %zu bytes of LDS", m->D, lds_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_mfma<MP, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_mfma<MP, RT, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
         attr_set = true;
     }
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;
     const int ngroups = (ntiles + RT - 1) / RT;
-    const int64_t nft = (T + FT - 1) / FT;
-    int64_t gx = (int64_t)(4 * ctx->num_cus + ngroups - 1) / ngroups;
-    if (gx > nft) gx = nft;
+    const int64_t nbt = (T + 4 * WF - 1) / (4 * WF);   // workgroup-sized frame tiles
+    // ~16 workgroups per resident slot (2 per CU) for load balance; each reloads a 40 KB parameter tile
+    int64_t gx = (int64_t)(32 * ctx->num_cus + ngroups - 1) / ngroups;
+    if (gx > nbt) gx = nbt;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((k_gmm_mfma<MP, RT>), dim3((unsigned)gx, (unsigned)ngroups), dim3(256), lds_bytes, ctx->stream, feats, ld, T,
-                       m->center, m->packed, m->D, m->G, out, ldo);
+    hipLaunchKernelGGL((k_gmm_mfma<MP, RT, CONTIG>), dim3((unsigned)gx, (unsigned)ngroups), dim3(256), lds_bytes, ctx->stream, feats,
+                       ld, T, m->center, m->packed, m->D, DP, m->G, out, st_t, st_g);
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
 
+template <int MP, int RT>
+static int launch_mfma(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t st_t, int64_t st_g) {
+    if (ld == m->D) return launch_mfma2<MP, RT, true>(ctx, m, feats, ld, T, out, st_t, st_g);
+    return launch_mfma2<MP, RT, false>(ctx, m, feats, ld, T, out, st_t, st_g);
+}
+
 template <int MP>
-static int dispatch_rt(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t ldo) {
+static int dispatch_rt(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t st_t, int64_t st_g) {
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;
-    if (ntiles >= 4) return launch_mfma<MP, 4>(ctx, m, feats, ld, T, out, ldo);
-    if (ntiles >= 2) return launch_mfma<MP, 2>(ctx, m, feats, ld, T, out, ldo);
-    return launch_mfma<MP, 1>(ctx, m, feats, ld, T, out, ldo);
+    if (ntiles >= 4) return launch_mfma<MP, 4>(ctx, m, feats, ld, T, out, st_t, st_g);
+    if (ntiles >= 2) return launch_mfma<MP, 2>(ctx, m, feats, ld, T, out, st_t, st_g);
+    return launch_mfma<MP, 1>(ctx, m, feats, ld, T, out, st_t, st_g);
 }
 
 extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
-                                 int64_t T, float *out_dev, int64_t ld_out) {
+                                 int64_t T, float *out_dev, int64_t stride_t, int64_t stride_g) {
     SRX_REQUIRE(nullptr, ctx, "srx_gmm_score_dev: null ctx");
     SRX_REQUIRE(ctx, m && feats_dev && out_dev, "srx_gmm_score_dev: null argument");
-    SRX_REQUIRE(ctx, ld >= m->D && ld_out >= m->G && T >= 0, "srx_gmm_score_dev: ld=%d < D=%d or ld_out < G", ld, m->D);
+    SRX_REQUIRE(ctx, ld >= m->D && T >= 0, "srx_gmm_score_dev: ld=%d < D=%d", ld, m->D);
+    SRX_REQUIRE(ctx, (stride_g == 1 && stride_t >= m->G) || (stride_t == 1 && stride_g >= T),
+                "srx_gmm_score_dev: output strides must be frame-major (stride_g=1, stride_t>=G) or state-major (stride_t=1, stride_g>=T)");
     SRX_REQUIRE(ctx, mix_mode == SRX_MIX_COMPONENT0 || mix_mode == SRX_MIX_LOGSUMEXP, "srx_gmm_score_dev: bad mix_mode");
     if (T == 0) return SRX_OK;
     if (score_path == SRX_SCORE_EXACT) {
         const int64_t n = T * m->G;
         SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_gmm_score_dev: too large");
         hipLaunchKernelGGL(k_gmm_exact, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats_dev, ld, T, m->G, m->M,
-                           m->D, m->mean, m->var, m->logwt, mix_mode, out_dev, ld_out);
+                           m->D, m->mean, m->var, m->logwt, mix_mode, out_dev, stride_t, stride_g);
         SRX_LAUNCH_CHECK(ctx);
         return SRX_OK;
     }
@@ -368,11 +445,11 @@ extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int s
     if (rc != SRX_OK) return rc;
     const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
     switch (padded_components(Muse)) {
-        case 1: return dispatch_rt<1>(ctx, m, feats_dev, ld, T, out_dev, ld_out);
-        case 2: return dispatch_rt<2>(ctx, m, feats_dev, ld, T, out_dev, ld_out);
-        case 4: return dispatch_rt<4>(ctx, m, feats_dev, ld, T, out_dev, ld_out);
-        case 8: return dispatch_rt<8>(ctx, m, feats_dev, ld, T, out_dev, ld_out);
-        case 16: return dispatch_rt<16>(ctx, m, feats_dev, ld, T, out_dev, ld_out);
+        case 1: return dispatch_rt<1>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
+        case 2: return dispatch_rt<2>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
+        case 4: return dispatch_rt<4>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
+        case 8: return dispatch_rt<8>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
+        case 16: return dispatch_rt<16>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
     }
     return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "srx_gmm_score_dev: unsupported component count");
 }
@@ -386,7 +463,7 @@ extern "C" int srx_gmm_score(srx_ctx *ctx, srx_model *m, int mix_mode, int score
     SRX_HIP(ctx, df.alloc((size_t)T * ld * sizeof(float)));
     SRX_HIP(ctx, dout.alloc((size_t)T * m->G * sizeof(float)));
     SRX_HIP(ctx, hipMemcpyAsync(df.p, feats, (size_t)T * ld * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    int rc = srx_gmm_score_dev(ctx, m, mix_mode, score_path, df.as<float>(), ld, T, dout.as<float>(), m->G);
+    int rc = srx_gmm_score_dev(ctx, m, mix_mode, score_path, df.as<float>(), ld, T, dout.as<float>(), m->G, 1);
     if (rc != SRX_OK) return rc;
     SRX_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)T * m->G * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -39,7 +39,7 @@ static constexpr int NEVER = 0x7fffffff;
 template <int SPL, bool BEAM>
 __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                                 const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
-                                                const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t ldE,
+                                                const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
                                                 float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
                                                 float *__restrict__ final_logp, int32_t *__restrict__ status) {
     const int u = blockIdx.x;
@@ -101,13 +101,16 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         has2[q] = (s < S && s >= 2) ? ntr[s0 + s - 2] == 3 : false;
     }
 
-    const float *erow = emis + f0 * ldE;
+    const float *erow = emis + f0 * st_t;
+    int64_t eoff[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; q++) eoff[q] = (int64_t)col[q] * st_g;
     float er[PF][SPL];
 #pragma unroll
     for (int p = 0; p < PF; p++) {
         const int tt = p < T ? p : (T > 0 ? T - 1 : 0);
 #pragma unroll
-        for (int q = 0; q < SPL; q++) er[p][q] = T > 0 ? erow[(int64_t)tt * ldE + col[q]] : 0.0f;
+        for (int q = 0; q < SPL; q++) er[p][q] = T > 0 ? erow[(int64_t)tt * st_t + eoff[q]] : 0.0f;
     }
 
     uint32_t bw[SPL];
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
                     int tn = t + PF;
                     if (tn >= T) tn = T - 1;
 #pragma unroll
-                    for (int q = 0; q < SPL; q++) er[p][q] = erow[(int64_t)tn * ldE + col[q]];
+                    for (int q = 0; q < SPL; q++) er[p][q] = erow[(int64_t)tn * st_t + eoff[q]];
                 }
                 bool ok[SPL];
                 float c0[SPL], c1[SPL], c2[SPL];
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(256) void k_train_transitions(int n_utt, const int6
     }
 }
 
-extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t ld_emis,
-                                     float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
+extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
+                                     int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
     SRX_REQUIRE(nullptr, ctx, "srx_viterbi_batch_dev: null ctx");
     SRX_REQUIRE(ctx, hmm && emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
     SRX_REQUIRE(ctx, hmm->frame_off_dev && hmm->state_off_dev && hmm->tied_dev && hmm->ntr_dev && hmm->trlogp_dev,
@@ -320,7 +323,7 @@ extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
     dim3 grid(hmm->n_utt), block(64);
 #define SRX_VIT(SPLV, BEAMV)                                                                                              \
     hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,            \
-                       hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, ld_emis, beam_width,   \
+                       hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
     if (spl == 1) { if (beam) SRX_VIT(1, true); else SRX_VIT(1, false); }
     else if (spl == 2) { if (beam) SRX_VIT(2, true); else SRX_VIT(2, false); }

@@ -234,9 +234,10 @@ class AcousticModel:
         check(self.ctx.lib.srx_gmm_score(self.ctx.h, self.h, mix_mode, path, _ptr(feats), ld, T, _ptr(out)), self.ctx.h)
         return out
 
-    def score_dev(self, feats_d, ld, T, out_d, ld_out, mix_mode=SRX_MIX_COMPONENT0, path=SRX_SCORE_MFMA):
-        check(self.ctx.lib.srx_gmm_score_dev(self.ctx.h, self.h, mix_mode, path, feats_d.ptr, ld, T, out_d.ptr, ld_out),
-              self.ctx.h)
+    def score_dev(self, feats_d, ld, T, out_d, stride_t, stride_g, mix_mode=SRX_MIX_COMPONENT0, path=SRX_SCORE_MFMA):
+        """Score (t, g) -> out[t*stride_t + g*stride_g] (frame-major: (G, 1); state-major: (1, T))."""
+        check(self.ctx.lib.srx_gmm_score_dev(self.ctx.h, self.h, mix_mode, path, feats_d.ptr, ld, T, out_d.ptr, stride_t,
+                                             stride_g), self.ctx.h)
 
 
 # ----------------------------------------------------------------------------- HMM batch
@@ -275,14 +276,15 @@ class HmmBatch:
     def trlogp(self):
         return self.trlogp_d.get()
 
-    def viterbi(self, emis_d, ld_emis, beam=1e10, path_d=None, final_d=None, status_d=None):
-        """hmm::viterbi for every utterance (src/hmm.cpp:150-224), emission matrix on the device."""
+    def viterbi(self, emis_d, stride_t, stride_g=1, beam=1e10, path_d=None, final_d=None, status_d=None):
+        """hmm::viterbi for every utterance (src/hmm.cpp:150-224); emission (t, col) at
+        emis[t*stride_t + col*stride_g] (frame-major [T, G]: (G, 1); state-major [G, T]: (1, T))."""
         ctx = self.ctx
         path_d = path_d or ctx.zeros((max(self.total_frames, 1),), np.int32)
         final_d = final_d or ctx.zeros((max(self.n_utt, 1),), np.float32)
         status_d = status_d or ctx.zeros((max(self.n_utt, 1),), np.int32)
-        check(ctx.lib.srx_viterbi_batch_dev(ctx.h, C.byref(self.c), emis_d.ptr, ld_emis, beam, path_d.ptr, final_d.ptr,
-                                            status_d.ptr), ctx.h)
+        check(ctx.lib.srx_viterbi_batch_dev(ctx.h, C.byref(self.c), emis_d.ptr, stride_t, stride_g, beam, path_d.ptr,
+                                            final_d.ptr, status_d.ptr), ctx.h)
         return path_d, final_d, status_d
 
     def train_transition_probabilities(self, path_d, status_d):

@@ -89,6 +89,25 @@ def test_ragged_T_and_ld(ctx, oracle):
     model.close()
 
 
+def test_state_major_output(ctx, oracle):
+    """srx_gmm_score_dev with (stride_t, stride_g) = (1, T): the transposed [G, T] layout."""
+    G, M, D, T = 37, 4, 39, 333
+    mean, var, w = synth.random_model(G, M, D, 9)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    feats = _feats(T, 39, 11)
+    ref = oracle.gmm_score(feats, mean, var, oracle.set_wt(w), D, 1)
+    f_d = ctx.array(feats)
+    for path, tol in ((SRX_SCORE_MFMA, 1e-4), (SRX_SCORE_EXACT, 1e-6)):
+        out_d = ctx.zeros((G, T), np.float32)
+        model.score_dev(f_d, 39, T, out_d, 1, T, SRX_MIX_LOGSUMEXP, path)
+        ctx.sync()
+        assert _close(out_d.get().T, ref, tol).all()
+    with pytest.raises(Exception):
+        model.score_dev(f_d, 39, T, ctx.zeros((G, T), np.float32), 2, 3)
+    model.close()
+
+
 def test_model_roundtrip_and_copy(ctx):
     G, M, D = 6, 3, 13
     mean, var, w = synth.random_model(G, M, D, 8)

@@ -27,10 +27,14 @@ def _make_batch(rng, n_utt, G, t_lo, t_hi, max_states=None, words=None):
     return phones, ntrs, trs, tieds, fo
 
 
-def _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam=1e10):
+def _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam=1e10, state_major=False):
     hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
-    emis_d = ctx.array(emis)
-    path_d, final_d, status_d = hb.viterbi(emis_d, emis.shape[1], beam)
+    if state_major:   # [G, T] layout, the one srx_gmm_score_dev writes fastest
+        emis_d = ctx.array(np.ascontiguousarray(emis.T))
+        path_d, final_d, status_d = hb.viterbi(emis_d, 1, emis.shape[0], beam)
+    else:
+        emis_d = ctx.array(emis)
+        path_d, final_d, status_d = hb.viterbi(emis_d, emis.shape[1], 1, beam)
     ctx.sync()
     path, final, status = path_d.get(), final_d.get(), status_d.get()
     for u in range(len(ntrs)):
@@ -52,6 +56,7 @@ def test_viterbi_bit_exact(ctx, oracle, words, spl):
     assert (mx > 64 * (spl // 2)) or spl == 1
     emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 20).astype(np.float32)
     _check(ctx, oracle, ntrs, trs, tieds, fo, emis)
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major=True)
 
 
 def test_viterbi_positive_scores_and_short_T(ctx, oracle):
