@@ -18,12 +18,12 @@ struct srx_ctx {
     int num_cus = 256;
     char err[512] = {0};
     // grow-only device workspace (Viterbi back-pointer words, ...)
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
+    void *ws[2] = {nullptr, nullptr};   // slot 0: GMM operand rows, slot 1: Viterbi back-pointers
+    size_t ws_bytes[2] = {0, 0};
 };
 
 // Returns a device workspace of at least `bytes` (contents undefined).  Grow-only, owned by ctx.
-int srx_workspace(srx_ctx *ctx, size_t bytes, void **out);
+int srx_workspace(srx_ctx *ctx, int slot, size_t bytes, void **out);
 
 extern char g_srx_create_err[512];
 

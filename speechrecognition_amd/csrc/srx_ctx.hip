@@ -44,21 +44,22 @@ extern "C" void srx_ctx_destroy(srx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (int i = 0; i < 2; i++)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     delete ctx;
 }
 
-int srx_workspace(srx_ctx *ctx, size_t bytes, void **out) {
-    if (bytes > ctx->ws_bytes) {
+int srx_workspace(srx_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes > ctx->ws_bytes[slot]) {
         SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->ws) (void)hipFree(ctx->ws);
-        ctx->ws = nullptr;
-        ctx->ws_bytes = 0;
+        if (ctx->ws[slot]) (void)hipFree(ctx->ws[slot]);
+        ctx->ws[slot] = nullptr;
+        ctx->ws_bytes[slot] = 0;
         size_t want = bytes + bytes / 4 + 4096;
-        SRX_HIP(ctx, hipMalloc(&ctx->ws, want));
-        ctx->ws_bytes = want;
+        SRX_HIP(ctx, hipMalloc(&ctx->ws[slot], want));
+        ctx->ws_bytes[slot] = want;
     }
-    *out = ctx->ws;
+    *out = ctx->ws[slot];
     return SRX_OK;
 }
 

@@ -17,10 +17,6 @@
 
 #include "srx_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-static constexpr float kNegInf = -__builtin_huge_valf();
-
 // ------------------------------------------------------------------------------------------
 // model bookkeeping
 // ------------------------------------------------------------------------------------------
@@ -137,291 +133,9 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float *__restrict__ fea
     out[t * st_t + (int64_t)g * st_g] = r;
 }
 
-// ------------------------------------------------------------------------------------------
-// MFMA path: packing
-// ------------------------------------------------------------------------------------------
-// centre[d] = f32( mean over all (g,m) of mean[g][m][d] ), one block per d.
-__global__ __launch_bounds__(256) void k_center(const double *__restrict__ mean, int n, int D, float *__restrict__ center) {
-    const int d = blockIdx.x;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        double v = mean[(size_t)i * D + d];
-        if (v == v && fabs(v) < 1e300) acc += v;  // NaN/inf means (unvisited states after EM) do not poison the shift
-    }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) center[d] = (float)((part[0] + part[1] + part[2] + part[3]) / n);
-}
-
-// Row i (0..31) of an MFMA tile lives in lane half hr = (i>>2)&1, accumulator register r = (i&3) + 4*(i>>3).
-// Register r of half hr holds component r%MP of tile-local state hr*(16/MP) + r/MP.
-// packed layout: [row tile][kstep s = 0..D][h = 0,1][row i = 0..31]
-//   s < D: h=0 -> coefficient of x'_d^2 = -1/(2 var), h=1 -> coefficient of x'_d = mu'/var
-//   s = D: h=0 -> constant term, h=1 -> 0
-__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ mean, const double *__restrict__ var,
-                                              const float *__restrict__ logwt, const float *__restrict__ center, int G, int M,
-                                              int D, int MP, int Muse, int ntiles, float *__restrict__ packed) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int KS = D + 1;
-    if (idx >= (int64_t)ntiles * KS * 64) return;
-    const int i = (int)(idx & 31);
-    const int h = (int)((idx >> 5) & 1);
-    const int s = (int)((idx >> 6) % KS);
-    const int tile = (int)((idx >> 6) / KS);
-    const int hr = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
-    const int st = hr * (16 / MP) + r / MP, c = r % MP;
-    const int g = tile * (32 / MP) + st;
-    float v;
-    if (g >= G || c >= Muse) {
-        v = (s == D && h == 0) ? kNegInf : 0.0f;
-    } else {
-        const size_t o = (size_t)g * M + c;
-        if (s < D) {
-            const double iv = 1.0 / var[o * D + s];
-            v = h == 0 ? (float)(-0.5 * iv) : (float)(iv * (mean[o * D + s] - (double)center[s]));
-        } else if (h == 1) {
-            v = 0.0f;
-        } else {
-            const double l2pi = (double)(float)-0.4515827052894549;
-            double acc = 0.0;
-            for (int d = 0; d < D; d++) {
-                const double mu = mean[o * D + d] - (double)center[d];
-                const double s2 = var[o * D + d];
-                acc += l2pi + log(s2) + mu * mu / s2;
-            }
-            v = (float)((double)logwt[o] - 0.5 * acc);
-        }
-    }
-    packed[idx] = v;
-}
-
-static int padded_components(int M) {
-    int mp = 1;
-    while (mp < M) mp <<= 1;
-    return mp;
-}
-
-static int ensure_packed(srx_ctx *ctx, srx_model *m, int mix_mode) {
-    const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
-    const int MP = padded_components(Muse);
-    if (MP > 16) return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "MFMA scoring supports at most 16 mixture components (got %d)", Muse);
-    if (!m->dirty && m->packed_mode == mix_mode && m->packed) return SRX_OK;
-    const int spt = 32 / MP;  // states per row tile
-    int ntiles = (m->G + spt - 1) / spt;
-    ntiles = (ntiles + 3) / 4 * 4;  // whole groups of 4 tiles so any RT divides
-    const size_t bytes = (size_t)ntiles * (m->D + 1) * 64 * sizeof(float);
-    if (bytes > m->packed_bytes) {
-        (void)hipFree(m->packed);
-        m->packed = nullptr;
-        m->packed_bytes = 0;
-        SRX_HIP(ctx, hipMalloc((void **)&m->packed, bytes));
-        m->packed_bytes = bytes;
-    }
-    hipLaunchKernelGGL(k_center, dim3(m->D), dim3(256), 0, ctx->stream, m->mean, m->G * m->M, m->D, m->center);
-    SRX_LAUNCH_CHECK(ctx);
-    const int64_t n = (int64_t)ntiles * (m->D + 1) * 64;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, m->mean, m->var, m->logwt, m->center,
-                       m->G, m->M, m->D, MP, Muse, ntiles, m->packed);
-    SRX_LAUNCH_CHECK(ctx);
-    m->dirty = false;
-    m->packed_mode = mix_mode;
-    return SRX_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// MFMA path: scoring kernel.  Workgroup = 4 waves sharing one parameter tile of RT row tiles
-// (32 Gaussians each) in LDS; every wave walks its own sequence of 32-frame tiles (no workgroup
-// barrier inside the loop, so the waves of a SIMD drift apart and one's epilogue/stores overlap
-// the other's MFMAs).  out element (t, g) lives at out[t*st_t + g*st_g]: st_t == 1 (state-major)
-// makes every store 128 contiguous bytes per half-wave.
-// ------------------------------------------------------------------------------------------
-static constexpr int WF = 32;        // frames per wave tile (MFMA columns)
-static constexpr int NXR = 20;       // staging registers per lane: covers WF*D <= 1280 (D <= 40) in one batch
-
-// Copies this wave's WF frames (rows of D floats, row stride ld) into its LDS slab xs[frame][DP]
-// through registers.  `load` issues the global loads (so they can fly during the MFMA loop of the
-// previous tile), `store` writes them to LDS.  Rows past T read as zero.
-template <bool CONTIG>
-__device__ __forceinline__ void stage_load(float (&rx)[NXR], const float *__restrict__ feats, int ld, int64_t T, int64_t t0, int D,
-                                           int lane, int batch) {
-    const int nel = WF * D;
-    const int64_t lim = (T - t0) * (int64_t)D;  // elements that exist (contiguous case)
-#pragma unroll
-    for (int i = 0; i < NXR; i++) {
-        const int idx = batch * (NXR * 64) + i * 64 + lane;
-        float v = 0.0f;
-        if (CONTIG) {
-            if (idx < nel && idx < lim) v = feats[t0 * ld + idx];
-        } else {
-            const int t = idx / D, d = idx - t * D;
-            if (idx < nel && t0 + t < T) v = feats[(t0 + t) * ld + d];
-        }
-        rx[i] = v;
-    }
-}
-template <bool CONTIG>
-__device__ __forceinline__ void stage_store(const float (&rx)[NXR], float *xs, int D, int DP, int lane, int batch) {
-    const int nel = WF * D;
-#pragma unroll
-    for (int i = 0; i < NXR; i++) {
-        const int idx = batch * (NXR * 64) + i * 64 + lane;
-        if (idx < nel) {
-            if (CONTIG && DP == D) {
-                xs[idx] = rx[i];
-            } else {
-                const int t = idx / D, d = idx - t * D;
-                xs[t * DP + d] = rx[i];
-            }
-        }
-    }
-}
-
-template <int MP, int RT, bool CONTIG>
-__global__ __launch_bounds__(256, 2) void k_gmm_mfma(const float *__restrict__ feats, int ld, int64_t T,
-                                                     const float *__restrict__ center, const float *__restrict__ packed, int D,
-                                                     int DP, int G, float *__restrict__ out, int64_t st_t, int64_t st_g) {
-    extern __shared__ float lds[];
-    const int KS = D + 1;
-    float *Pl = lds;                                   // [RT][KS][64]
-    float *cl = lds + RT * KS * 64;                    // [D] centring vector
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float *xs = cl + ((D + 3) & ~3) + w * (WF * DP);   // this wave's [WF][DP] (DP odd: conflict-free column reads)
-    const int j = lane & 31, h = lane >> 5;
-
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)blockIdx.y * RT * KS * 64);
-        float4 *dst = reinterpret_cast<float4 *>(Pl);
-        const int n4 = RT * KS * 16;
-        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
-        for (int i = tid; i < D; i += 256) cl[i] = center[i];
-    }
-    __syncthreads();
-    const int64_t nwt = (T + WF - 1) / WF;
-    constexpr int NST = 16 / MP;          // states per lane half per row tile
-    constexpr int SPT = 32 / MP;          // states per row tile
-    const float *pl = Pl + lane;
-    const float *xrow = xs + j * DP;
-    const int nbatch = (WF * D + NXR * 64 - 1) / (NXR * 64);
-    const int64_t wstride = (int64_t)gridDim.x * 4;
-    int64_t wt = (int64_t)blockIdx.x * 4 + w;
-    float rx[NXR];
-    if (wt < nwt) stage_load<CONTIG>(rx, feats, ld, T, wt * WF, D, lane, 0);
-    for (; wt < nwt; wt += wstride) {
-        const int64_t t0 = wt * WF;
-        // ---- finish staging tile wt (batch 0 is already in registers) ----
-        stage_store<CONTIG>(rx, xs, D, DP, lane, 0);
-        for (int bt = 1; bt < nbatch; bt++) {
-            stage_load<CONTIG>(rx, feats, ld, T, t0, D, lane, bt);
-            stage_store<CONTIG>(rx, xs, D, DP, lane, bt);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- prefetch the next tile's first batch; it lands while the MFMAs run ----
-        if (wt + wstride < nwt) stage_load<CONTIG>(rx, feats, ld, T, (wt + wstride) * WF, D, lane, 0);
-
-        f32x16 acc[RT];
-#pragma unroll
-        for (int r = 0; r < RT; r++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[r][e] = 0.0f;
-        // software-pipelined k loop: operands of step s+1 are read while step s multiplies
-        float an[RT], xn, cn;
-#pragma unroll
-        for (int r = 0; r < RT; r++) an[r] = pl[(r * KS) * 64];
-        xn = xrow[0];
-        cn = cl[0];
-        for (int s = 0; s < D; s++) {
-            float ac[RT];
-#pragma unroll
-            for (int r = 0; r < RT; r++) ac[r] = an[r];
-            const float xv = xn - cn;
-            const int sn = s + 1;
-#pragma unroll
-            for (int r = 0; r < RT; r++) an[r] = pl[(r * KS + sn) * 64];
-            if (sn < D) {
-                xn = xrow[sn];
-                cn = cl[sn];
-            }
-            const float b = h ? xv : xv * xv;
-#pragma unroll
-            for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[r], b, acc[r], 0, 0, 0);
-        }
-        {
-            const float b = h ? 0.0f : 1.0f;
-#pragma unroll
-            for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(an[r], b, acc[r], 0, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- epilogue: per-state log-sum-exp over the lane's registers, then store ----
-        const int64_t fr = t0 + j;
-        if (fr < T) {
-            float *orow = out + fr * st_t;
-#pragma unroll
-            for (int r = 0; r < RT; r++) {
-                const int gbase = ((int)blockIdx.y * RT + r) * SPT + h * NST;
-#pragma unroll
-                for (int st = 0; st < NST; st++) {
-                    float v;
-                    if (MP == 1) {
-                        v = acc[r][st];
-                    } else {
-                        float mx = acc[r][st * MP];
-#pragma unroll
-                        for (int c = 1; c < MP; c++) mx = fmaxf(mx, acc[r][st * MP + c]);
-                        float sum = 0.0f;
-#pragma unroll
-                        for (int c = 0; c < MP; c++) sum += __expf(acc[r][st * MP + c] - mx);
-                        v = mx + __logf(sum);
-                    }
-                    const int g = gbase + st;
-                    if (g < G) orow[(int64_t)g * st_g] = v;
-                }
-            }
-        }
-    }
-}
-
-template <int MP, int RT, bool CONTIG>
-static int launch_mfma2(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t st_t, int64_t st_g) {
-    const int KS = m->D + 1;
-    const int DP = m->D | 1;  // odd row stride
-    const size_t lds_bytes = ((size_t)RT * KS * 64 + ((m->D + 3) & ~3) + (size_t)4 * WF * DP) * sizeof(float);
-    SRX_REQUIRE(ctx, lds_bytes <= 160 * 1024, "srx_gmm_score: D=%d needs %zu bytes of LDS", m->D, lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_mfma<MP, RT, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-        attr_set = true;
-    }
-    const int spt = 32 / MP;
-    const int ntiles = (m->G + spt - 1) / spt;
-    const int ngroups = (ntiles + RT - 1) / RT;
-    const int64_t nbt = (T + 4 * WF - 1) / (4 * WF);   // workgroup-sized frame tiles
-    // ~16 workgroups per resident slot (2 per CU) for load balance; each reloads a 40 KB parameter tile
-    int64_t gx = (int64_t)(32 * ctx->num_cus + ngroups - 1) / ngroups;
-    if (gx > nbt) gx = nbt;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((k_gmm_mfma<MP, RT, CONTIG>), dim3((unsigned)gx, (unsigned)ngroups), dim3(256), lds_bytes, ctx->stream, feats,
-                       ld, T, m->center, m->packed, m->D, DP, m->G, out, st_t, st_g);
-    SRX_LAUNCH_CHECK(ctx);
-    return SRX_OK;
-}
-
-template <int MP, int RT>
-static int launch_mfma(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t st_t, int64_t st_g) {
-    if (ld == m->D) return launch_mfma2<MP, RT, true>(ctx, m, feats, ld, T, out, st_t, st_g);
-    return launch_mfma2<MP, RT, false>(ctx, m, feats, ld, T, out, st_t, st_g);
-}
-
-template <int MP>
-static int dispatch_rt(srx_ctx *ctx, srx_model *m, const float *feats, int ld, int64_t T, float *out, int64_t st_t, int64_t st_g) {
-    const int spt = 32 / MP;
-    const int ntiles = (m->G + spt - 1) / spt;
-    if (ntiles >= 4) return launch_mfma<MP, 4>(ctx, m, feats, ld, T, out, st_t, st_g);
-    if (ntiles >= 2) return launch_mfma<MP, 2>(ctx, m, feats, ld, T, out, st_t, st_g);
-    return launch_mfma<MP, 1>(ctx, m, feats, ld, T, out, st_t, st_g);
-}
+// MFMA path: srx_gmm_mfma.hip
+int srx_gmm_score_mfma(srx_ctx *ctx, srx_model *m, int mix_mode, const float *feats, int ld, int64_t T, float *out, int64_t st_t,
+                       int64_t st_g);
 
 extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
                                  int64_t T, float *out_dev, int64_t stride_t, int64_t stride_g) {
@@ -441,17 +155,7 @@ extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int s
         return SRX_OK;
     }
     SRX_REQUIRE(ctx, score_path == SRX_SCORE_MFMA, "srx_gmm_score_dev: bad score_path");
-    int rc = ensure_packed(ctx, m, mix_mode);
-    if (rc != SRX_OK) return rc;
-    const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
-    switch (padded_components(Muse)) {
-        case 1: return dispatch_rt<1>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
-        case 2: return dispatch_rt<2>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
-        case 4: return dispatch_rt<4>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
-        case 8: return dispatch_rt<8>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
-        case 16: return dispatch_rt<16>(ctx, m, feats_dev, ld, T, out_dev, stride_t, stride_g);
-    }
-    return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "srx_gmm_score_dev: unsupported component count");
+    return srx_gmm_score_mfma(ctx, m, mix_mode, feats_dev, ld, T, out_dev, stride_t, stride_g);
 }
 
 extern "C" int srx_gmm_score(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats, int ld, int64_t T,

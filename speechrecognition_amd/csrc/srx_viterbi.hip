@@ -317,7 +317,7 @@ extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
     const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : 4);
     const size_t words = ((size_t)(total_frames >> 4) + (size_t)hmm->n_utt + 1) * 64 * spl;
     void *ws = nullptr;
-    int rc = srx_workspace(ctx, words * sizeof(uint32_t), &ws);
+    int rc = srx_workspace(ctx, 1, words * sizeof(uint32_t), &ws);
     if (rc != SRX_OK) return rc;
     const bool beam = beam_width < 1e10f;
     dim3 grid(hmm->n_utt), block(64);
