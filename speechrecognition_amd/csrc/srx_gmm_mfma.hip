@@ -9,14 +9,15 @@
 //
 // Three launches:
 //   k_center / k_pack  (only when the model changed)  parameters -> packed A operand, MFMA lane order
-//   k_gmm_prep         features -> operand rows Xc[T][KP] = (x'^2_d, x'_d interleaved, 1, 0...), 324 B/frame
+//   k_gmm_prep         features -> centred operand rows Xc[T][KP] = (x'_0 .. x'_{D-1}, 1, 0...), 164 B/frame at D = 39
 //   k_gmm_mfma         the contraction on v_mfma_f32_32x32x2_f32 + in-lane log-sum-exp + store
 //
 // k_gmm_mfma: workgroup = 8 waves (one per CU, two per SIMD) sharing one parameter tile of RT row
 // tiles (32 Gaussians each) in LDS.  Every wave walks its own sequence of 32-frame tiles: the tile's
-// operand rows are contiguous in Xc and are copied into the wave's LDS slab by LDS-DMA
-// (global_load_lds_dwordx4: no VGPRs, no VALU), issued as soon as the previous tile's last operand has
-// been read so that it flies under the epilogue and under the other wave's MFMAs.  Gaussians are the
+// operand rows are contiguous in Xc and are copied into one of the wave's two LDS slabs by LDS-DMA
+// (global_load_lds_dwordx4: no VGPRs, no VALU) a whole tile ahead, so the copy flies under the MFMAs;
+// the wave waits with a counted vmcnt that leaves its own output stores in flight.  x'^2 is formed in
+// registers (lanes 0-31 feed the quadratic row of a k-step, lanes 32-63 the linear one).  Gaussians are the
 // MFMA rows and frames the columns, so one lane's 16 accumulator registers hold the components of whole
 // states for one frame: the mixture log-sum-exp needs no cross-lane traffic.  No workgroup barrier
 // inside the loop: the two waves of a SIMD drift apart and overlap MFMA with VALU/stores.
@@ -29,7 +30,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static constexpr float kNegInf = -__builtin_huge_valf();
 static constexpr int WF = 32;      // frames per wave tile (MFMA columns)
 static constexpr int NW = 8;       // waves per workgroup
-static constexpr float kLog2e = 1.44269504088896340736f;
 static constexpr float kLn2 = 0.69314718055994530942f;
 
 // centre[d] = f32( mean over all (g,m) of mean[g][m][d] ), one block per d.
@@ -124,7 +124,7 @@ static int ensure_packed(srx_ctx *ctx, srx_model *m, int mix_mode, int KSP) {
     return SRX_OK;
 }
 
-// Operand rows: Xc[t][k], k < KP:  k = 2d -> x'_d^2, 2d+1 -> x'_d (d < D), k = 2D -> 1, everything else 0.
+// Operand rows: Xc[t][k], k < KP:  k < D -> x'_k = x_k - c_k, k = D -> 1 (the constant's k-step), else 0.
 // Rows T .. Tpad-1 (padding to whole wave tiles) are all zero.
 __global__ __launch_bounds__(256) void k_gmm_prep(const float *__restrict__ feats, int ld, int64_t T, int64_t Tpad, int D, int KP,
                                                   const float *__restrict__ center, float *__restrict__ Xc) {
@@ -134,100 +134,124 @@ __global__ __launch_bounds__(256) void k_gmm_prep(const float *__restrict__ feat
     const int k = (int)(idx - t * KP);
     float v = 0.0f;
     if (t < T) {
-        const int d = k >> 1;
-        if (d < D) {
-            const float x = feats[t * ld + d] - center[d];
-            v = (k & 1) ? x : x * x;
-        } else if (k == 2 * D) {
+        if (k < D)
+            v = feats[t * ld + k] - center[k];
+        else if (k == D)
             v = 1.0f;
-        }
     }
     Xc[idx] = v;
 }
 
 template <int MP, int RT>
-__global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ Xc, int64_t T, int64_t nwt,
+__global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ Xc, int64_t T, int64_t nwt, int ngroups,
                                                      const float *__restrict__ packed, int KSP, int KP, int slab, int ndma, int G,
-                                                     float *__restrict__ out, int64_t st_t, int64_t st_g) {
+                                                     float *__restrict__ out, int64_t st_t, int64_t st_g, float *__restrict__ dump) {
     extern __shared__ float lds[];
     float *Pl = lds;                                   // [RT][KSP][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *xs = lds + RT * KSP * 64 + w * slab;        // this wave's [WF][KP] operand rows (KP odd: conflict-free)
+    float *xs = lds + RT * KSP * 64 + w * (2 * slab);  // this wave's two [WF][KP] slabs (KP odd: conflict-free)
     const int j = lane & 31, h = lane >> 5;
-
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)blockIdx.y * RT * KSP * 64);
-        float4 *dst = reinterpret_cast<float4 *>(Pl);
-        const int n4 = RT * KSP * 16;
-        for (int i = tid; i < n4; i += 512) dst[i] = src[i];
-    }
-    __syncthreads();
     constexpr int NST = 16 / MP;          // states per lane half per row tile
     constexpr int SPT = 32 / MP;          // states per row tile
+    constexpr int NSTORE = RT * NST > 63 ? 63 : RT * NST;  // stores per tile per lane (vmcnt is 6 bits)
     const float *pl = Pl + lane;
-    const float *xrow = xs + j * KP + h;  // element (2s + h) of frame j is xrow[2s]
     const int nblk = KSP / 4;             // even
-    const int64_t wstride = (int64_t)gridDim.x * NW;
     const size_t tile_floats = (size_t)WF * KP;
 
-    auto dma = [&](int64_t wt) {
-        // one wave tile = WF*KP contiguous floats of Xc -> this wave's slab, 1 KiB per instruction
+    auto dma = [&](int64_t wt, int buf) {
+        // one wave tile = WF*KP contiguous floats of Xc -> one of this wave's slabs, 1 KiB per instruction
         const char *g = reinterpret_cast<const char *>(Xc + wt * tile_floats) + lane * 16;
+        float *dst = xs + buf * slab;
         for (int i = 0; i < ndma; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i * 1024),
-                                             (__attribute__((address_space(3))) void *)(xs + i * 256), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
     };
 
-    int64_t wt = (int64_t)blockIdx.x * NW + w;
-    if (wt < nwt) dma(wt);
-    for (; wt < nwt; wt += wstride) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's operand rows have landed
-        __builtin_amdgcn_wave_barrier();
+    // Static, even partition of the (parameter group, wave tile) space over the workgroups: the grid
+    // is one workgroup per CU, and workgroup b owns the contiguous range [lo, hi) of group-major tile
+    // indices, so it reloads the parameter tile only when its range crosses into the next group.
+    const int64_t ntot = (int64_t)ngroups * nwt;
+    const int64_t lo = ntot * blockIdx.x / gridDim.x, hi = ntot * (blockIdx.x + 1) / gridDim.x;
+    for (int64_t base = lo; base < hi;) {
+        const int grp = (int)(base / nwt);
+        const int64_t t_lo = base - (int64_t)grp * nwt;
+        const int64_t t_hi = (hi - (int64_t)grp * nwt) < nwt ? (hi - (int64_t)grp * nwt) : nwt;
+        base = (int64_t)grp * nwt + t_hi;
 
-        f32x16 acc[RT];
-        float a0[4][RT], x0[4], a1[4][RT], x1[4];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave is done with the previous parameter tile
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(packed + (size_t)grp * RT * KSP * 64);
+            float4 *dst = reinterpret_cast<float4 *>(Pl);
+            const int n4 = RT * KSP * 16;
+            for (int i = tid; i < n4; i += 64 * NW) dst[i] = src[i];
+        }
+        __syncthreads();
+
+        int64_t wt = t_lo + w;
+        int buf = 0;
+        if (wt < t_hi) dma(wt, 0);
+        bool first = true;
+        for (; wt < t_hi; wt += NW, buf ^= 1) {
+            // in flight, oldest first: [this tile's DMA][previous tile's NSTORE stores]: wait for the DMA only
+            // (a counted wait is only safe when at least NSTORE younger operations exist: not on the first pass)
+            if (first)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+            first = false;
+            __builtin_amdgcn_wave_barrier();
+            // next tile -> the other slab (its last reader was the k-loop two tiles ago); clamped so the
+            // number of outstanding operations is the same on the last pass
+            dma(wt + NW < t_hi ? wt + NW : wt, buf ^ 1);
+
+            const float *xrow = xs + buf * slab + j * KP;
+            f32x16 acc[RT];
+            float a0[4][RT], x0[4], a1[4][RT], x1[4];
 #define SRX_LDBLK(A, X, BLK)                                                            \
     _Pragma("unroll") for (int u = 0; u < 4; u++) {                                     \
-        X[u] = xrow[((BLK) * 4 + u) * 2];                                               \
+        X[u] = xrow[(BLK) * 4 + u];                                                     \
         _Pragma("unroll") for (int r = 0; r < RT; r++) A[u][r] = pl[(r * KSP + (BLK) * 4 + u) * 64]; \
     }
+#define SRX_B(X) (h ? (X) : (X) * (X))
 #define SRX_MMBLK(A, X)                                                                 \
     _Pragma("unroll") for (int u = 0; u < 4; u++) {                                     \
+        const float b = SRX_B(X[u]);                                                    \
         _Pragma("unroll") for (int r = 0; r < RT; r++)                                  \
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][r], X[u], acc[r], 0, 0, 0); \
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][r], b, acc[r], 0, 0, 0); \
     }
-        SRX_LDBLK(a0, x0, 0)
-        SRX_LDBLK(a1, x1, 1)
-        {
-            const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            SRX_LDBLK(a0, x0, 0)
+            SRX_LDBLK(a1, x1, 1)
+            {
+                const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const float b0 = SRX_B(x0[0]);
 #pragma unroll
-            for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0][r], x0[0], z, 0, 0, 0);
+                for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0][r], b0, z, 0, 0, 0);
 #pragma unroll
-            for (int u = 1; u < 4; u++)
+                for (int u = 1; u < 4; u++) {
+                    const float b = SRX_B(x0[u]);
 #pragma unroll
-                for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][r], x0[u], acc[r], 0, 0, 0);
-        }
-        for (int blk = 2; blk < nblk; blk += 2) {
-            SRX_LDBLK(a0, x0, blk)
+                    for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][r], b, acc[r], 0, 0, 0);
+                }
+            }
+            for (int blk = 2; blk < nblk; blk += 2) {
+                SRX_LDBLK(a0, x0, blk)
+                SRX_MMBLK(a1, x1)
+                SRX_LDBLK(a1, x1, blk + 1)
+                SRX_MMBLK(a0, x0)
+            }
             SRX_MMBLK(a1, x1)
-            SRX_LDBLK(a1, x1, blk + 1)
-            SRX_MMBLK(a0, x0)
-        }
-        SRX_MMBLK(a1, x1)
 #undef SRX_LDBLK
 #undef SRX_MMBLK
-        // every operand of this tile has been read: refill the slab with the wave's next tile
-        asm volatile("" ::: "memory");
-        if (wt + wstride < nwt) dma(wt + wstride);
-
-        // ---- epilogue: per-state log-sum-exp over the lane's registers, then store ----
-        const int64_t fr = wt * WF + j;
-        if (fr < T) {
+#undef SRX_B
+            // ---- epilogue: per-state log-sum-exp over the lane's registers, then exactly NSTORE stores ----
+            const int64_t fr = wt * WF + j;
             float *orow = out + fr * st_t;
+            int nst = 0;
 #pragma unroll
             for (int r = 0; r < RT; r++) {
-                const int gbase = ((int)blockIdx.y * RT + r) * SPT + h * NST;
+                const int gbase = (grp * RT + r) * SPT + h * NST;
 #pragma unroll
                 for (int st = 0; st < NST; st++) {
                     float v;
@@ -243,7 +267,10 @@ __global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ X
                         v = (mx + __builtin_amdgcn_logf(sum)) * kLn2;
                     }
                     const int g = gbase + st;
-                    if (g < G) orow[(int64_t)g * st_g] = v;
+                    // out-of-range lanes store to a dump slot instead of branching, so the count stays exact
+                    float *dst = (fr < T && g < G) ? orow + (int64_t)g * st_g : dump + lane;
+                    if (nst < NSTORE || (fr < T && g < G)) *dst = v;
+                    nst++;
                 }
             }
         }
@@ -252,10 +279,10 @@ __global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ X
 
 template <int MP, int RT>
 static int launch_mfma(srx_ctx *ctx, srx_model *m, const float *Xc, int64_t T, int64_t nwt, int KSP, int KP, float *out,
-                       int64_t st_t, int64_t st_g) {
+                       int64_t st_t, int64_t st_g, float *dump) {
     const int ndma = (WF * KP * 4 + 1023) / 1024;
     const int slab = ndma * 256;  // floats; the last DMA piece may overrun the tile, never the slab
-    const size_t lds_bytes = ((size_t)RT * KSP * 64 + (size_t)NW * slab + 64) * sizeof(float);
+    const size_t lds_bytes = ((size_t)RT * KSP * 64 + (size_t)NW * 2 * slab + 64) * sizeof(float);
     SRX_REQUIRE(ctx, lds_bytes <= 160 * 1024, "srx_gmm_score: D=%d needs %zu bytes of LDS (max 160 KiB)", m->D, lds_bytes);
     static bool attr_set = false;
     if (!attr_set) {
@@ -265,40 +292,41 @@ static int launch_mfma(srx_ctx *ctx, srx_model *m, const float *Xc, int64_t T, i
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;
     const int ngroups = (ntiles + RT - 1) / RT;
-    const int64_t nbt = (nwt + NW - 1) / NW;  // workgroup-sized frame tiles
-    // ~8 workgroups per CU over the launch for load balance; each reloads one parameter tile (<= 40 KiB)
-    int64_t gx = (int64_t)(8 * ctx->num_cus + ngroups - 1) / ngroups;
-    if (gx > nbt) gx = nbt;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((k_gmm_mfma<MP, RT>), dim3((unsigned)gx, (unsigned)ngroups), dim3(64 * NW), lds_bytes, ctx->stream, Xc, T, nwt,
-                       m->packed, KSP, KP, slab, ndma, m->G, out, st_t, st_g);
+    const int64_t ntot = (int64_t)ngroups * nwt;
+    int64_t nb = ctx->num_cus;  // one 8-wave workgroup per CU, each with an equal share of the tile space
+    if (nb > (ntot + NW - 1) / NW) nb = (ntot + NW - 1) / NW;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL((k_gmm_mfma<MP, RT>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, ctx->stream, Xc, T, nwt, ngroups,
+                       m->packed, KSP, KP, slab, ndma, m->G, out, st_t, st_g, dump);
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
 
 template <int MP>
 static int dispatch_rt(srx_ctx *ctx, srx_model *m, const float *Xc, int64_t T, int64_t nwt, int KSP, int KP, float *out,
-                       int64_t st_t, int64_t st_g) {
+                       int64_t st_t, int64_t st_g, float *dump) {
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;
-    if (ntiles >= 4) return launch_mfma<MP, 4>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
-    if (ntiles >= 2) return launch_mfma<MP, 2>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
-    return launch_mfma<MP, 1>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
+    if (ntiles >= 4) return launch_mfma<MP, 4>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
+    if (ntiles >= 2) return launch_mfma<MP, 2>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
+    return launch_mfma<MP, 1>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
 }
 
 // Called by srx_gmm_score_dev (srx_gmm.hip) after argument validation.
 int srx_gmm_score_mfma(srx_ctx *ctx, srx_model *m, int mix_mode, const float *feats, int ld, int64_t T, float *out, int64_t st_t,
                        int64_t st_g) {
     const int KSP = (m->D + 1 + 7) / 8 * 8;  // k-steps, padded to two register blocks of four
-    const int KP = 2 * KSP + 1;              // operand row length (odd)
+    const int KP = KSP + 1;                  // operand row length (odd): x'_0..x'_{D-1}, 1, 0...
     int rc = ensure_packed(ctx, m, mix_mode, KSP);
     if (rc != SRX_OK) return rc;
     const int64_t nwt = (T + WF - 1) / WF;
     const int64_t Tpad = nwt * WF;
     void *ws = nullptr;
-    rc = srx_workspace(ctx, 0, ((size_t)Tpad * KP + 1024) * sizeof(float), &ws);  // +4 KiB: the last DMA piece reads past the tile
+    // +4 KiB: the last DMA piece of a tile reads past it; +256 B: dump slots for out-of-range lanes' stores
+    rc = srx_workspace(ctx, 0, ((size_t)Tpad * KP + 1024 + 64) * sizeof(float), &ws);
     if (rc != SRX_OK) return rc;
     float *Xc = reinterpret_cast<float *>(ws);
+    float *dump = Xc + (size_t)Tpad * KP + 1024;
     const int64_t n = Tpad * KP;
     SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_gmm_score: too many frames");
     hipLaunchKernelGGL(k_gmm_prep, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats, ld, T, Tpad, m->D, KP,
@@ -306,11 +334,11 @@ int srx_gmm_score_mfma(srx_ctx *ctx, srx_model *m, int mix_mode, const float *fe
     SRX_LAUNCH_CHECK(ctx);
     const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
     switch (padded_components(Muse)) {
-        case 1: return dispatch_rt<1>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
-        case 2: return dispatch_rt<2>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
-        case 4: return dispatch_rt<4>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
-        case 8: return dispatch_rt<8>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
-        case 16: return dispatch_rt<16>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g);
+        case 1: return dispatch_rt<1>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
+        case 2: return dispatch_rt<2>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
+        case 4: return dispatch_rt<4>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
+        case 8: return dispatch_rt<8>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
+        case 16: return dispatch_rt<16>(ctx, m, Xc, T, nwt, KSP, KP, out, st_t, st_g, dump);
     }
     return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "srx_gmm_score: unsupported component count");
 }
