@@ -48,6 +48,20 @@ def build_workload(n_utt, seed):
     return x, soff, ntrs, trs, tieds
 
 
+def pmc_traffic(kernel, T):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/pmc_traffic.json, written by
+    tools/pmc_traffic.py from separate `rocprofv3 --pmc` runs of this same workload; the counters cannot be
+    collected from inside this process).  None when no pass is on record for this frame count."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(kernel)
+        if rec and int(rec.get("frames", -1)) == int(T):
+            return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(x, soff, ntrs, trs, tieds, model, budget_s=20.0):
     """Times the oracle (kind "port") end to end on a bounded sample of the same utterances."""
     from oracle import oracle as O
@@ -175,6 +189,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
+    ctx.profile_enable(True)   # HIP event pairs around every kernel launch, on the launch stream
     t0 = time.perf_counter()
     evs = [step(True) for _ in range(args.steps)]
     barrier()
@@ -182,6 +197,13 @@ def main():
     for e in evs:
         for k, name in enumerate(("mfcc", "features", "gmm", "viterbi")):
             stage_ms[name] += e[k].elapsed_time(e[k + 1]) / args.steps
+
+    kernel_ms = {}
+    for k in ("k_sumsq_scale", "k_mfcc_tile", "k_features", "k_gmm_prep", "k_gmm_mfma", "k_viterbi"):
+        ms, n = ctx.profile_query(k)
+        assert n == args.steps, (k, n)
+        kernel_ms[k] = ms / n
+    ctx.profile_enable(False)
 
     status = status_d.get()
     assert (status == 0).all(), "alignment failed for some utterance"
@@ -198,8 +220,9 @@ def main():
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
         flop_per_frame = 2.0 * (2 * D + 1) * G * M          # GMM scoring, all states
-        gmm_tflops = flop_per_frame * T / (stage_ms["gmm"] * 1e-3) / 1e12
+        gmm_tflops = flop_per_frame * T / (kernel_ms["k_gmm_mfma"] * 1e-3) / 1e12
         mfcc_bytes = (HOP * 4 + NCEPS * 4) * T               # 692 B/frame
+        mfcc_ms, vit_ms = kernel_ms["k_mfcc_tile"], kernel_ms["k_viterbi"]
         vit_S = float(np.mean([len(n) for n in ntrs]))
         vit_bytes = (4.25 * vit_S + 5) * T
         out = {
@@ -214,15 +237,17 @@ def main():
                        "utterances_per_gpu": n_utt, "frames_per_gpu": T, "window": WL, "hop": HOP, "G": G, "M": M, "D": D,
                        "mean_states_per_utt": vit_S, "parallelism": f"utterance-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": gmm_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gmm_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "k_gmm_mfma<16,4>", "flop_per_frame": flop_per_frame, "ms_per_launch": stage_ms["gmm"]},
-            "stages_ms": stage_ms,
+                         "frac": gmm_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("k_gmm_mfma", T),
+                         "kernel": "k_gmm_mfma<16,4>", "flop_per_frame": flop_per_frame,
+                         "ms_per_launch": kernel_ms["k_gmm_mfma"]},
+            "stages_ms": stage_ms, "kernels_ms": kernel_ms,
             "stage_rooflines": {
-                "mfcc_hbm": {"achieved_GBs": mfcc_bytes / (stage_ms["mfcc"] * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,
-                             "frac": mfcc_bytes / (stage_ms["mfcc"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_frame": 692},
-                "viterbi_hbm": {"achieved_GBs": vit_bytes / (stage_ms["viterbi"] * 1e-3) / 1e9, "peak_GBs": PEAK_HBM_GBS,
-                                "frac": vit_bytes / (stage_ms["viterbi"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                "bytes_per_frame": 4.25 * vit_S + 5},
+                "mfcc_hbm": {"kernel": "k_mfcc_tile", "achieved_GBs": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9,
+                             "peak_GBs": PEAK_HBM_GBS, "frac": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                             "bytes_per_frame": 692, "traffic": pmc_traffic("k_mfcc_tile", T)},
+                "viterbi_hbm": {"kernel": "k_viterbi", "achieved_GBs": vit_bytes / (vit_ms * 1e-3) / 1e9,
+                                "peak_GBs": PEAK_HBM_GBS, "frac": vit_bytes / (vit_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "bytes_per_frame": 4.25 * vit_S + 5, "traffic": pmc_traffic("k_viterbi", T)},
             },
         }
         if world == 1 and not args.no_cpu:

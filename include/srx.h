@@ -46,6 +46,15 @@ const char *srx_last_error(const srx_ctx *ctx); /* ctx may be NULL: last creatio
 int srx_sync(srx_ctx *ctx);
 const char *srx_version(void);
 
+/* Per-kernel timing with HIP events on the context's stream.  No counterpart in the reference (which has
+ * only a commented-out clock() print, src/mfcc.cpp:260,268-270); bench.py's roofline figures come from it.
+ * srx_profile_enable(ctx, 1) clears the records and starts bracketing every kernel launch of this
+ * context with an event pair; srx_profile_query synchronises the stream and returns the summed
+ * duration and launch count of the kernel with that name ("k_gmm_mfma", "k_mfcc_tile", "k_viterbi",
+ * "k_features", "k_gmm_prep", "k_sumsq_scale", "k_em_logp", "k_em_accum1", "k_em_accum2", ...). */
+int srx_profile_enable(srx_ctx *ctx, int on);
+int srx_profile_query(srx_ctx *ctx, const char *kernel, double *total_ms, int64_t *launches);
+
 /* Device-memory plumbing so that C/C++ callers need no HIP headers. */
 int srx_malloc(srx_ctx *ctx, size_t bytes, void **dev);
 int srx_free(srx_ctx *ctx, void *dev);

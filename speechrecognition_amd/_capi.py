@@ -49,6 +49,8 @@ SIGNATURES = {
     "srx_last_error": (C.c_char_p, [vp]),
     "srx_sync": (C.c_int, [vp]),
     "srx_version": (C.c_char_p, []),
+    "srx_profile_enable": (C.c_int, [vp, C.c_int]),
+    "srx_profile_query": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),
     "srx_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "srx_free": (C.c_int, [vp, vp]),
     "srx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),

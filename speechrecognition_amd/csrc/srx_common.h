@@ -20,6 +20,29 @@ struct srx_ctx {
     // grow-only device workspace (Viterbi back-pointer words, ...)
     void *ws[2] = {nullptr, nullptr};   // slot 0: GMM operand rows, slot 1: Viterbi back-pointers
     size_t ws_bytes[2] = {0, 0};
+    // per-kernel timing (srx_profile_enable / srx_profile_query): event pairs recorded on `stream`
+    struct prof_rec {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    bool prof_on = false;
+    std::vector<prof_rec> prof;
+};
+
+// Brackets one kernel launch with events on the context's stream while profiling is enabled.
+struct SrxProf {
+    srx_ctx *c;
+    hipEvent_t b = nullptr;
+    SrxProf(srx_ctx *ctx, const char *name) : c(ctx) {
+        if (!c->prof_on) return;
+        hipEvent_t a = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { b = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+        c->prof.push_back({name, a, b});
+    }
+    ~SrxProf() {
+        if (b) (void)hipEventRecord(b, c->stream);
+    }
 };
 
 // Returns a device workspace of at least `bytes` (contents undefined).  Grow-only, owned by ctx.

@@ -46,7 +46,35 @@ extern "C" void srx_ctx_destroy(srx_ctx *ctx) {
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     for (int i = 0; i < 2; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     delete ctx;
+}
+
+extern "C" int srx_profile_enable(srx_ctx *ctx, int on) {
+    SRX_REQUIRE(nullptr, ctx, "srx_profile_enable: null ctx");
+    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    ctx->prof.clear();
+    ctx->prof_on = on != 0;
+    return SRX_OK;
+}
+
+extern "C" int srx_profile_query(srx_ctx *ctx, const char *kernel, double *total_ms, int64_t *launches) {
+    SRX_REQUIRE(nullptr, ctx, "srx_profile_query: null ctx");
+    SRX_REQUIRE(ctx, kernel && total_ms && launches, "srx_profile_query: null argument");
+    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double ms = 0.0;
+    int64_t n = 0;
+    for (auto &r : ctx->prof)
+        if (strcmp(r.name, kernel) == 0) {
+            float t = 0.0f;
+            SRX_HIP(ctx, hipEventElapsedTime(&t, r.a, r.b));
+            ms += t;
+            n++;
+        }
+    *total_ms = ms;
+    *launches = n;
+    return SRX_OK;
 }
 
 int srx_workspace(srx_ctx *ctx, int slot, size_t bytes, void **out) {

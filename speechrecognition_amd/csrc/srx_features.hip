@@ -72,8 +72,11 @@ extern "C" int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const fl
     const int64_t nthr = total_frames * n_ceps;
     const int64_t nblk = ceil_div64(nthr, 256);
     SRX_REQUIRE(ctx, nblk < (1ll << 31), "srx_features_batch_dev: too many frames");
-    hipLaunchKernelGGL(k_features, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ceps_dev, frame_off_dev, n_utt, total_frames,
-                       n_ceps, WL, feats_dev);
+    {
+        SrxProf prof_(ctx, "k_features");
+        hipLaunchKernelGGL(k_features, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ceps_dev, frame_off_dev, n_utt, total_frames,
+                           n_ceps, WL, feats_dev);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
@@ -129,9 +132,15 @@ extern "C" int srx_corpus_mean_var_dev(srx_ctx *ctx, const float *feats_dev, int
     SRX_REQUIRE(ctx, feats_dev && sum_dev && D >= 1 && ld >= D && total_frames >= 1, "srx_corpus_mean_var_dev: bad argument");
     SRX_HIP(ctx, hipMemsetAsync(sum_dev, 0, 2 * D * sizeof(double), ctx->stream));
     int nb = (int)(ceil_div64(total_frames, 256) < 1024 ? ceil_div64(total_frames, 256) : 1024);
-    hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev, 0);
+    {
+        SrxProf prof_(ctx, "k_colsum");
+        hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev, 0);
+    }
     SRX_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev + D, 1);
+    {
+        SrxProf prof_(ctx, "k_colsum");
+        hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev + D, 1);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }

@@ -149,8 +149,11 @@ extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int s
     if (score_path == SRX_SCORE_EXACT) {
         const int64_t n = T * m->G;
         SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_gmm_score_dev: too large");
-        hipLaunchKernelGGL(k_gmm_exact, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats_dev, ld, T, m->G, m->M,
-                           m->D, m->mean, m->var, m->logwt, mix_mode, out_dev, stride_t, stride_g);
+        {
+            SrxProf prof_(ctx, "k_gmm_exact");
+            hipLaunchKernelGGL(k_gmm_exact, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats_dev, ld, T, m->G, m->M,
+                               m->D, m->mean, m->var, m->logwt, mix_mode, out_dev, stride_t, stride_g);
+        }
         SRX_LAUNCH_CHECK(ctx);
         return SRX_OK;
     }

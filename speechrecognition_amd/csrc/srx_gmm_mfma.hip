@@ -113,11 +113,17 @@ static int ensure_packed(srx_ctx *ctx, srx_model *m, int mix_mode, int KSP) {
         SRX_HIP(ctx, hipMalloc((void **)&m->packed, bytes));
         m->packed_bytes = bytes;
     }
-    hipLaunchKernelGGL(k_center, dim3(m->D), dim3(256), 0, ctx->stream, m->mean, m->G * m->M, m->D, m->center);
+    {
+        SrxProf prof_(ctx, "k_center");
+        hipLaunchKernelGGL(k_center, dim3(m->D), dim3(256), 0, ctx->stream, m->mean, m->G * m->M, m->D, m->center);
+    }
     SRX_LAUNCH_CHECK(ctx);
     const int64_t n = (int64_t)ntiles * KSP * 64;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, m->mean, m->var, m->logwt, m->center,
-                       m->G, m->M, m->D, KSP, MP, Muse, ntiles, m->packed);
+    {
+        SrxProf prof_(ctx, "k_pack");
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, m->mean, m->var, m->logwt, m->center,
+                           m->G, m->M, m->D, KSP, MP, Muse, ntiles, m->packed);
+    }
     SRX_LAUNCH_CHECK(ctx);
     m->dirty = false;
     m->packed_mode = mix_mode;
@@ -296,8 +302,11 @@ static int launch_mfma(srx_ctx *ctx, srx_model *m, const float *Xc, int64_t T, i
     int64_t nb = ctx->num_cus;  // one 8-wave workgroup per CU, each with an equal share of the tile space
     if (nb > (ntot + NW - 1) / NW) nb = (ntot + NW - 1) / NW;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL((k_gmm_mfma<MP, RT>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, ctx->stream, Xc, T, nwt, ngroups,
-                       m->packed, KSP, KP, slab, ndma, m->G, out, st_t, st_g, dump);
+    {
+        SrxProf prof_(ctx, "k_gmm_mfma");
+        hipLaunchKernelGGL((k_gmm_mfma<MP, RT>), dim3((unsigned)nb), dim3(64 * NW), lds_bytes, ctx->stream, Xc, T, nwt, ngroups,
+                           m->packed, KSP, KP, slab, ndma, m->G, out, st_t, st_g, dump);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
@@ -329,8 +338,11 @@ int srx_gmm_score_mfma(srx_ctx *ctx, srx_model *m, int mix_mode, const float *fe
     float *dump = Xc + (size_t)Tpad * KP + 1024;
     const int64_t n = Tpad * KP;
     SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_gmm_score: too many frames");
-    hipLaunchKernelGGL(k_gmm_prep, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats, ld, T, Tpad, m->D, KP,
-                       m->center, Xc);
+    {
+        SrxProf prof_(ctx, "k_gmm_prep");
+        hipLaunchKernelGGL(k_gmm_prep, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats, ld, T, Tpad, m->D, KP,
+                           m->center, Xc);
+    }
     SRX_LAUNCH_CHECK(ctx);
     const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
     switch (padded_components(Muse)) {

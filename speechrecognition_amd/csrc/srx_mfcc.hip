@@ -357,8 +357,11 @@ extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const
     const srx_mfcc_cfg &c = plan->cfg;
     if (c.normalize) {
         SRX_REQUIRE(ctx, scratch_scale_dev, "srx_mfcc_batch_dev: normalize needs scratch_scale_dev");
-        hipLaunchKernelGGL(k_sumsq_scale, dim3(n_utt), dim3(1024), 0, ctx->stream, samples_dev, sample_off_dev, c.target_rms,
-                           scratch_scale_dev);
+        {
+            SrxProf prof_(ctx, "k_sumsq_scale");
+            hipLaunchKernelGGL(k_sumsq_scale, dim3(n_utt), dim3(1024), 0, ctx->stream, samples_dev, sample_off_dev, c.target_rms,
+                               scratch_scale_dev);
+        }
         SRX_LAUNCH_CHECK(ctx);
     }
     MfccArgs a;
@@ -380,7 +383,10 @@ extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const
     }
     const int64_t nblk = ceil_div64(total_frames, TILE_F);
     SRX_REQUIRE(ctx, nblk < (1ll << 31), "srx_mfcc_batch_dev: too many frames");
-    hipLaunchKernelGGL(k_mfcc_tile, dim3((unsigned)nblk), dim3(256), lds_bytes, ctx->stream, a);
+    {
+        SrxProf prof_(ctx, "k_mfcc_tile");
+        hipLaunchKernelGGL(k_mfcc_tile, dim3((unsigned)nblk), dim3(256), lds_bytes, ctx->stream, a);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
@@ -416,10 +422,16 @@ extern "C" int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const 
     SRX_REQUIRE(nullptr, ctx, "srx_normalize_volume_dev: null ctx");
     SRX_REQUIRE(ctx, samples_dev && sample_off_dev && scratch_scale_dev && n_utt >= 0, "srx_normalize_volume_dev: bad argument");
     if (n_utt == 0) return SRX_OK;
-    hipLaunchKernelGGL(k_sumsq_scale, dim3(n_utt), dim3(1024), 0, ctx->stream, samples_dev, sample_off_dev, target_rms,
-                       scratch_scale_dev);
+    {
+        SrxProf prof_(ctx, "k_sumsq_scale");
+        hipLaunchKernelGGL(k_sumsq_scale, dim3(n_utt), dim3(1024), 0, ctx->stream, samples_dev, sample_off_dev, target_rms,
+                           scratch_scale_dev);
+    }
     SRX_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(k_apply_scale, dim3(64, n_utt), dim3(256), 0, ctx->stream, samples_dev, sample_off_dev, scratch_scale_dev);
+    {
+        SrxProf prof_(ctx, "k_apply_scale");
+        hipLaunchKernelGGL(k_apply_scale, dim3(64, n_utt), dim3(256), 0, ctx->stream, samples_dev, sample_off_dev, scratch_scale_dev);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
@@ -430,7 +442,10 @@ extern "C" int srx_preemphasis_dev(srx_ctx *ctx, float *samples_dev, float *scra
     SRX_REQUIRE(ctx, samples_dev && scratch_dev && sample_off_dev && n_utt >= 0 && total_samples >= 0,
                 "srx_preemphasis_dev: bad argument");
     if (n_utt == 0 || total_samples == 0) return SRX_OK;
-    hipLaunchKernelGGL(k_preemph, dim3(64, n_utt), dim3(256), 0, ctx->stream, samples_dev, scratch_dev, sample_off_dev, alpha);
+    {
+        SrxProf prof_(ctx, "k_preemph");
+        hipLaunchKernelGGL(k_preemph, dim3(64, n_utt), dim3(256), 0, ctx->stream, samples_dev, scratch_dev, sample_off_dev, alpha);
+    }
     SRX_LAUNCH_CHECK(ctx);
     SRX_HIP(ctx, hipMemcpyAsync(samples_dev, scratch_dev, total_samples * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     return SRX_OK;

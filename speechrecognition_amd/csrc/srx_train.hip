@@ -174,8 +174,11 @@ extern "C" int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
     SRX_REQUIRE(nullptr, ctx, "srx_em_gather_gid_dev: null ctx");
     SRX_REQUIRE(ctx, hmm && path_dev && status_dev && gid_dev && total_frames >= 0, "srx_em_gather_gid_dev: bad argument");
     if (total_frames == 0 || hmm->n_utt == 0) return SRX_OK;
-    hipLaunchKernelGGL(k_gather_gid, dim3((unsigned)ceil_div64(total_frames, 256)), dim3(256), 0, ctx->stream, hmm->n_utt,
-                       hmm->frame_off_dev, hmm->state_off_dev, hmm->tied_dev, path_dev, status_dev, total_frames, gid_dev);
+    {
+        SrxProf prof_(ctx, "k_gather_gid");
+        hipLaunchKernelGGL(k_gather_gid, dim3((unsigned)ceil_div64(total_frames, 256)), dim3(256), 0, ctx->stream, hmm->n_utt,
+                           hmm->frame_off_dev, hmm->state_off_dev, hmm->tied_dev, path_dev, status_dev, total_frames, gid_dev);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
@@ -184,14 +187,20 @@ extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
                                 float *logp_dev, float *shift_dev) {
     SRX_REQUIRE(nullptr, ctx, "srx_em_shift_dev: null ctx");
     SRX_REQUIRE(ctx, A && feats_dev && gid_dev && logp_dev && shift_dev && T >= 0 && ld >= A->D, "srx_em_shift_dev: bad argument");
-    hipLaunchKernelGGL(k_fill_f32, dim3((A->G * A->M + 255) / 256), dim3(256), 0, ctx->stream, shift_dev, -__builtin_huge_valf(),
-                       A->G * A->M);
+    {
+        SrxProf prof_(ctx, "k_fill_f32");
+        hipLaunchKernelGGL(k_fill_f32, dim3((A->G * A->M + 255) / 256), dim3(256), 0, ctx->stream, shift_dev, -__builtin_huge_valf(),
+                           A->G * A->M);
+    }
     SRX_LAUNCH_CHECK(ctx);
     if (T == 0) return SRX_OK;
     const int64_t n = T * A->M;
     SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_em_shift_dev: too large");
-    hipLaunchKernelGGL(k_em_logp, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats_dev, ld, gid_dev, T, A->M, A->D,
-                       A->mean, A->var, A->logwt, logp_dev, shift_dev);
+    {
+        SrxProf prof_(ctx, "k_em_logp");
+        hipLaunchKernelGGL(k_em_logp, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats_dev, ld, gid_dev, T, A->M, A->D,
+                           A->mean, A->var, A->logwt, logp_dev, shift_dev);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
@@ -210,11 +219,17 @@ static int launch_accum(srx_ctx *ctx, srx_model *A, srx_model *B, const float *f
     if (nb < 1) nb = 1;
     const double *meanB = B ? B->mean : nullptr;
     if (bytes <= 64 * 1024) {
-        hipLaunchKernelGGL((k_em_accum<PASS, true>), dim3((unsigned)nb), dim3(256), bytes, ctx->stream, feats, ld, gid, T, A->M, A->D,
-                           nrows, A->weight, logp, shift, meanB, stats);
+        {
+            SrxProf prof_(ctx, PASS == 1 ? "k_em_accum1" : "k_em_accum2");
+            hipLaunchKernelGGL((k_em_accum<PASS, true>), dim3((unsigned)nb), dim3(256), bytes, ctx->stream, feats, ld, gid, T, A->M, A->D,
+                               nrows, A->weight, logp, shift, meanB, stats);
+        }
     } else {
-        hipLaunchKernelGGL((k_em_accum<PASS, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, feats, ld, gid, T, A->M, A->D,
-                           nrows, A->weight, logp, shift, meanB, stats);
+        {
+            SrxProf prof_(ctx, PASS == 1 ? "k_em_accum1" : "k_em_accum2");
+            hipLaunchKernelGGL((k_em_accum<PASS, false>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, feats, ld, gid, T, A->M, A->D,
+                               nrows, A->weight, logp, shift, meanB, stats);
+        }
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
@@ -232,8 +247,11 @@ extern "C" int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1
     SRX_REQUIRE(nullptr, ctx, "srx_em_means_dev: null ctx");
     SRX_REQUIRE(ctx, B && stats1_dev && shift_dev, "srx_em_means_dev: null argument");
     const int64_t n = (int64_t)B->G * B->M * B->D;
-    hipLaunchKernelGGL(k_em_means, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev, shift_dev,
-                       B->mean, B->var, B->weight, B->logwt);
+    {
+        SrxProf prof_(ctx, "k_em_means");
+        hipLaunchKernelGGL(k_em_means, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev, shift_dev,
+                           B->mean, B->var, B->weight, B->logwt);
+    }
     SRX_LAUNCH_CHECK(ctx);
     B->dirty = true;
     return SRX_OK;
@@ -254,8 +272,11 @@ extern "C" int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const
     SRX_REQUIRE(ctx, A && B && stats1_dev && stats2_dev, "srx_em_finish_dev: null argument");
     SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_finish_dev: model shape mismatch");
     const int64_t n = (int64_t)B->G * B->M * B->D;
-    hipLaunchKernelGGL(k_em_finish, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev,
-                       stats2_dev, A->mean, A->var, A->weight, B->mean, B->var, B->weight, B->logwt, blend_keep);
+    {
+        SrxProf prof_(ctx, "k_em_finish");
+        hipLaunchKernelGGL(k_em_finish, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, B->G, B->M, B->D, stats1_dev,
+                           stats2_dev, A->mean, A->var, A->weight, B->mean, B->var, B->weight, B->logwt, blend_keep);
+    }
     SRX_LAUNCH_CHECK(ctx);
     B->dirty = true;
     return SRX_OK;

@@ -325,9 +325,12 @@ extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
     hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,            \
                        hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
-    if (spl == 1) { if (beam) SRX_VIT(1, true); else SRX_VIT(1, false); }
-    else if (spl == 2) { if (beam) SRX_VIT(2, true); else SRX_VIT(2, false); }
-    else { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
+    {
+        SrxProf prof_(ctx, "k_viterbi");
+        if (spl == 1) { if (beam) SRX_VIT(1, true); else SRX_VIT(1, false); }
+        else if (spl == 2) { if (beam) SRX_VIT(2, true); else SRX_VIT(2, false); }
+        else { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
+    }
 #undef SRX_VIT
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
@@ -339,8 +342,11 @@ extern "C" int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm,
     SRX_REQUIRE(ctx, hmm && path_dev && status_dev, "srx_train_transitions_dev: null argument");
     SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 256, "srx_train_transitions_dev: max_states outside 1..256");
     if (hmm->n_utt == 0) return SRX_OK;
-    hipLaunchKernelGGL(k_train_transitions, dim3(hmm->n_utt), dim3(256), 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,
-                       hmm->state_off_dev, hmm->ntr_dev, hmm->trlogp_dev, path_dev, status_dev);
+    {
+        SrxProf prof_(ctx, "k_train_transitions");
+        hipLaunchKernelGGL(k_train_transitions, dim3(hmm->n_utt), dim3(256), 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,
+                           hmm->state_off_dev, hmm->ntr_dev, hmm->trlogp_dev, path_dev, status_dev);
+    }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }

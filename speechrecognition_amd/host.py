@@ -39,6 +39,16 @@ class Context:
     def sync(self):
         check(self.lib.srx_sync(self.h), self.h)
 
+    def profile_enable(self, on=True):
+        """Start (and clear) / stop per-kernel event timing on this context's stream."""
+        check(self.lib.srx_profile_enable(self.h, int(on)), self.h)
+
+    def profile_query(self, kernel):
+        """(total_ms, launches) of `kernel` since profile_enable(True); synchronises the stream."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self.lib.srx_profile_query(self.h, kernel.encode(), C.byref(ms), C.byref(n)), self.h)
+        return ms.value, n.value
+
     # --- device arrays ---
     def empty(self, shape, dtype):
         return DevArray(self, shape, dtype)
