@@ -29,7 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr float kNegInf = -__builtin_huge_valf();
 static constexpr int WF = 32;      // frames per wave tile (MFMA columns)
-static constexpr int NW = 8;       // waves per workgroup
+#ifndef SRX_V_NW
+#define SRX_V_NW 8
+#endif
+static constexpr int NW = SRX_V_NW;       // waves per workgroup
 static constexpr float kLn2 = 0.69314718055994530942f;
 
 // centre[d] = f32( mean over all (g,m) of mean[g][m][d] ), one block per d.
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(256) void k_center(const double *__restrict__ mean,
 
 // Row i (0..31) of an MFMA tile lives in lane half hr = (i>>2)&1, accumulator register r = (i&3) + 4*(i>>3).
 // Register r of half hr holds component r%MP of tile-local state hr*(16/MP) + r/MP.
-// packed layout: [row tile][kstep s = 0..KSP)[h = 0,1][row i = 0..31]
+// packed layout: [row tile][k block = s/4][h = 0,1][row i = 0..31][u = s%4]: the four k-steps of a register block are
+// one 16-byte LDS read per lane (ds_read_b128)
 //   s < D : h=0 -> coefficient of x'_d^2 = -1/(2 var), h=1 -> coefficient of x'_d = mu'/var
 //   s = D : h=0 -> constant term, h=1 -> 0;   s > D : 0 (K padded to a multiple of 8 steps)
 // With more than one component everything is pre-multiplied by log2(e): the accumulators are then
@@ -59,10 +63,12 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ mean, c
                                               int D, int KSP, int MP, int Muse, int ntiles, float *__restrict__ packed) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)ntiles * KSP * 64) return;
-    const int i = (int)(idx & 31);
-    const int h = (int)((idx >> 5) & 1);
-    const int s = (int)((idx >> 6) % KSP);
-    const int tile = (int)((idx >> 6) / KSP);
+    const int u = (int)(idx & 3);
+    const int i = (int)((idx >> 2) & 31);
+    const int h = (int)((idx >> 7) & 1);
+    const int kblk = (int)((idx >> 8) % (KSP / 4));
+    const int tile = (int)((idx >> 8) / (KSP / 4));
+    const int s = kblk * 4 + u;
     const int hr = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
     const int st = hr * (16 / MP) + r / MP, c = r % MP;
     const int g = tile * (32 / MP) + st;
@@ -148,12 +154,19 @@ __global__ __launch_bounds__(256) void k_gmm_prep(const float *__restrict__ feat
     Xc[idx] = v;
 }
 
+// -DSRX_V_STAMP builds a diagnostic variant that prints, for one workgroup, the shader cycles each wave spent
+// waiting for its operand DMA, in the k loop and in the epilogue (s_memtime stamps; never enabled in libsrx.so).
+#ifdef SRX_V_STAMP
+#define SRX_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define SRX_STAMP(var)
+#endif
 template <int MP, int RT>
-__global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ Xc, int64_t T, int64_t nwt, int ngroups,
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_gmm_mfma(const float *__restrict__ Xc, int64_t T, int64_t nwt, int ngroups,
                                                      const float *__restrict__ packed, int KSP, int KP, int slab, int ndma, int G,
                                                      float *__restrict__ out, int64_t st_t, int64_t st_g, float *__restrict__ dump) {
-    extern __shared__ float lds[];
-    float *Pl = lds;                                   // [RT][KSP][64]
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Pl = lds;                                   // [RT][KSP/4][64][4]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *xs = lds + RT * KSP * 64 + w * (2 * slab);  // this wave's two [WF][KP] slabs (KP odd: conflict-free)
@@ -161,7 +174,8 @@ __global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ X
     constexpr int NST = 16 / MP;          // states per lane half per row tile
     constexpr int SPT = 32 / MP;          // states per row tile
     constexpr int NSTORE = RT * NST > 63 ? 63 : RT * NST;  // stores per tile per lane (vmcnt is 6 bits)
-    const float *pl = Pl + lane;
+    int *ctr = reinterpret_cast<int *>(lds + RT * KSP * 64 + NW * 2 * slab);  // tile hand-out counter
+    const float4 *pl4 = reinterpret_cast<const float4 *>(Pl) + lane;
     const int nblk = KSP / 4;             // even
     const size_t tile_floats = (size_t)WF * KP;
 
@@ -177,6 +191,7 @@ __global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ X
     // Static, even partition of the (parameter group, wave tile) space over the workgroups: the grid
     // is one workgroup per CU, and workgroup b owns the contiguous range [lo, hi) of group-major tile
     // indices, so it reloads the parameter tile only when its range crosses into the next group.
+    // Inside a workgroup the tiles are handed to the waves dynamically (see below).
     const int64_t ntot = (int64_t)ngroups * nwt;
     const int64_t lo = ntot * blockIdx.x / gridDim.x, hi = ntot * (blockIdx.x + 1) / gridDim.x;
     for (int64_t base = lo; base < hi;) {
@@ -192,14 +207,27 @@ __global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ X
             float4 *dst = reinterpret_cast<float4 *>(Pl);
             const int n4 = RT * KSP * 16;
             for (int i = tid; i < n4; i += 64 * NW) dst[i] = src[i];
+            if (tid == 0) *ctr = 0;
         }
         __syncthreads();
 
-        int64_t wt = t_lo + w;
+        // Tiles of this segment are numbered 0 .. nseg-1.  The first NW are handed out statically (wave w
+        // takes tile w); after that every wave draws its next tile from an LDS counter one tile ahead of
+        // need.  The older wave of a SIMD wins the MFMA arbitration and runs faster than the younger one:
+        // with a static split it would finish early and leave the younger wave running alone.
+        const int nseg = (int)(t_hi - t_lo);
+        int cur = w;
         int buf = 0;
-        if (wt < t_hi) dma(wt, 0);
+        if (cur < nseg) dma(t_lo + cur, 0);
+#ifdef SRX_V_STAMP
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, sum_wait = 0, sum_k = 0, sum_epi = 0, ntile = 0, tbeg = 0, tend = 0;
+        SRX_STAMP(tbeg)
+#endif
         bool first = true;
-        for (; wt < t_hi; wt += NW, buf ^= 1) {
+        for (; cur < nseg; buf ^= 1) {
+            SRX_STAMP(ts0)
+            int drawn = 0;
+            if (lane == 0) drawn = atomicAdd(ctr, 1);
             // in flight, oldest first: [this tile's DMA][previous tile's NSTORE stores]: wait for the DMA only
             // (a counted wait is only safe when at least NSTORE younger operations exist: not on the first pass)
             if (first)
@@ -208,49 +236,62 @@ __global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ X
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
             first = false;
             __builtin_amdgcn_wave_barrier();
-            // next tile -> the other slab (its last reader was the k-loop two tiles ago); clamped so the
-            // number of outstanding operations is the same on the last pass
-            dma(wt + NW < t_hi ? wt + NW : wt, buf ^ 1);
+            const int nxt = NW + __builtin_amdgcn_readfirstlane(drawn);
+            const int64_t wt = t_lo + cur;
+            // next tile -> the other slab (its last reader was the k-loop two tiles ago); on the last pass the
+            // current tile is fetched again so that the number of outstanding operations stays the same
+            dma(nxt < nseg ? t_lo + nxt : wt, buf ^ 1);
 
+            SRX_STAMP(ts1)
             const float *xrow = xs + buf * slab + j * KP;
             f32x16 acc[RT];
             float a0[4][RT], x0[4], a1[4][RT], x1[4];
-#define SRX_LDBLK(A, X, BLK)                                                            \
-    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                     \
-        X[u] = xrow[(BLK) * 4 + u];                                                     \
-        _Pragma("unroll") for (int r = 0; r < RT; r++) A[u][r] = pl[(r * KSP + (BLK) * 4 + u) * 64]; \
-    }
+            const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SRX_SB __builtin_amdgcn_sched_barrier(0);
 #define SRX_B(X) (h ? (X) : (X) * (X))
-#define SRX_MMBLK(A, X)                                                                 \
-    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                     \
-        const float b = SRX_B(X[u]);                                                    \
-        _Pragma("unroll") for (int r = 0; r < RT; r++)                                  \
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u][r], b, acc[r], 0, 0, 0); \
+            // One k block = 4 k-steps x RT row tiles = 4*RT MFMAs on operands already in registers, with the
+            // NEXT block's LDS reads (RT x ds_read_b128 of parameters, 2 x ds_read2_b32 of x) spread one or two
+            // per group of RT MFMAs and the order pinned.  Left to itself the scheduler either sinks each read
+            // next to its use (exposed LDS latency) or clumps them between blocks, and six back-to-back LDS
+            // reads stall the wave's own MFMA stream.  (Measured with tools/microbench/mfma_f32_issue.hip: a wave's
+            // VALU instructions do NOT hide under its own f32-input MFMAs on gfx950 -- about 5.5 cycles each are
+            // added -- only another wave of the SIMD overlaps them, hence two waves per SIMD and as few VALU
+            // instructions per k-step as possible.)
+#define SRX_BLOCK(AC, XC, AN, XN, BN, LOADNEXT, ZERO)                                                   \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                     \
+        if (LOADNEXT) {                                                                                 \
+            _Pragma("unroll") for (int r = u; r < RT; r += 4) {                                         \
+                const float4 q = pl4[(r * nblk + (BN)) * 64];                                           \
+                AN[0][r] = q.x; AN[1][r] = q.y; AN[2][r] = q.z; AN[3][r] = q.w;                         \
+            }                                                                                           \
+            if (u < 2) {                                                                                \
+                XN[2 * u] = xrow[(BN) * 4 + 2 * u];                                                     \
+                XN[2 * u + 1] = xrow[(BN) * 4 + 2 * u + 1];                                             \
+            }                                                                                           \
+        }                                                                                               \
+        const float b = SRX_B(XC[u]);                                                                   \
+        _Pragma("unroll") for (int r = 0; r < RT; r++)                                                  \
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(AC[u][r], b, ((ZERO) && u == 0) ? z : acc[r], 0, 0, 0); \
+        SRX_SB                                                                                          \
     }
-            SRX_LDBLK(a0, x0, 0)
-            SRX_LDBLK(a1, x1, 1)
-            {
-                const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                const float b0 = SRX_B(x0[0]);
 #pragma unroll
-                for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0][r], b0, z, 0, 0, 0);
+            for (int u = 0; u < 4; u++) x0[u] = xrow[u];
 #pragma unroll
-                for (int u = 1; u < 4; u++) {
-                    const float b = SRX_B(x0[u]);
-#pragma unroll
-                    for (int r = 0; r < RT; r++) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][r], b, acc[r], 0, 0, 0);
-                }
+            for (int r = 0; r < RT; r++) {
+                const float4 q = pl4[(r * nblk) * 64];
+                a0[0][r] = q.x; a0[1][r] = q.y; a0[2][r] = q.z; a0[3][r] = q.w;
             }
-            for (int blk = 2; blk < nblk; blk += 2) {
-                SRX_LDBLK(a0, x0, blk)
-                SRX_MMBLK(a1, x1)
-                SRX_LDBLK(a1, x1, blk + 1)
-                SRX_MMBLK(a0, x0)
+            SRX_SB
+            SRX_BLOCK(a0, x0, a1, x1, 1, true, true)
+            for (int blk = 1; blk < nblk - 1; blk += 2) {
+                SRX_BLOCK(a1, x1, a0, x0, blk + 1, true, false)
+                SRX_BLOCK(a0, x0, a1, x1, blk + 2, true, false)
             }
-            SRX_MMBLK(a1, x1)
-#undef SRX_LDBLK
-#undef SRX_MMBLK
+            SRX_BLOCK(a1, x1, a0, x0, 0, false, false)
+#undef SRX_SB
+#undef SRX_BLOCK
 #undef SRX_B
+            SRX_STAMP(ts2)
             // ---- epilogue: per-state log-sum-exp over the lane's registers, then exactly NSTORE stores ----
             const int64_t fr = wt * WF + j;
             float *orow = out + fr * st_t;
@@ -279,7 +320,18 @@ __global__ __launch_bounds__(512, 2) void k_gmm_mfma(const float *__restrict__ X
                     nst++;
                 }
             }
+#ifdef SRX_V_STAMP
+            SRX_STAMP(ts3)
+            sum_wait += ts1 - ts0; sum_k += ts2 - ts1; sum_epi += ts3 - ts2; ntile++;
+#endif
+            cur = nxt;
         }
+#ifdef SRX_V_STAMP
+        SRX_STAMP(tend)
+        if (blockIdx.x == 7 && lane == 0)
+            printf("wave %d tiles %llu total %llu wait %llu kloop %llu epi %llu (per tile: total %llu wait %llu k %llu epi %llu)\n", w, ntile, tend - tbeg,
+                   sum_wait, sum_k, sum_epi, (tend - tbeg) / (ntile ? ntile : 1), sum_wait / (ntile ? ntile : 1), sum_k / (ntile ? ntile : 1), sum_epi / (ntile ? ntile : 1));
+#endif
     }
 }
 
