@@ -68,6 +68,11 @@ typedef struct {
     float center, width, height;
 } srx_filter;
 
+/* filter::filter(c, w, dft_bins, sps)  src/mfcc.cpp:117-128: centre/width in Hz -> bins (ofMap), height
+ * normalised over the filter's own bin range.  filter::get(bin)  src/mfcc.cpp:132-140.  Host-side. */
+int srx_filter_init(float center_hz, float width_hz, int dft_bins, int sps, srx_filter *out);
+float srx_filter_value(const srx_filter *f, int bin);
+
 /* mel_filterbank(end, n, dft_bins, sps)  src/mfcc.cpp:190-201 (+ filter ctor :117-128,
  * ofMap of OpenFrameworks).  Host-side constants; writes n filters and bin_max
  * (src/mfcc.cpp:220-221). */
@@ -117,6 +122,11 @@ int srx_mfcc_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples
 /* Clip::rmsAmplitude + Clip::normalizeVolume  src/clip.cpp:151-164 (in place, per utterance) */
 int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt,
                              float target_rms, float *scratch_scale_dev);
+/* Clip::operator*=(float)  src/clip.cpp:144-148 per utterance: samples of utterance u *= scale_dev[u]. */
+int srx_scale_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt, const float *scale_dev);
+/* Clip::rmsAmplitude  src/clip.cpp:157-164 per utterance: rms_dev[u] = sqrt(sum of squares) (no 1/N). */
+int srx_rms_amplitude_dev(srx_ctx *ctx, const float *samples_dev, const int64_t *sample_off_dev, int n_utt,
+                          double *rms_dev);
 /* Clip::preemphasis  src/clip.cpp:199-205 (in place, per utterance; needs a same-size scratch) */
 int srx_preemphasis_dev(srx_ctx *ctx, float *samples_dev, float *scratch_dev, const int64_t *sample_off_dev,
                         int n_utt, int64_t total_samples, float alpha);
@@ -196,6 +206,13 @@ int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
  * utterance whose status is 0. */
 int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,
                               const int32_t *status_dev);
+
+/* state_model::augment over every frame of every final path  src/hmm.cpp:46-51, 350-356 (the tail of
+ * hmm::train): cls[n_states] = tied class of each state under the state model's ties (-1: skip);
+ * probsum[c] += exp(tr[1]) (hmm_state::get_adv_prob), count[c] += 1.  state_model::operator()
+ * (src/hmm.cpp:39-44) is then probsum/count, 0.5 where count == 0.  Sums are f64 (reference: f32). */
+int srx_state_model_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *cls_dev, const int32_t *path_dev,
+                        const int32_t *status_dev, int n_classes, double *probsum_dev, int32_t *count_dev);
 
 /* ---------------------------------------------------------------- embedded training -- */
 /* The statistics half of one EM iteration, hmm::train src/hmm.cpp:274-341, split at the two

@@ -56,6 +56,8 @@ SIGNATURES = {
     "srx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "srx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "srx_memset": (C.c_int, [vp, vp, C.c_int, C.c_size_t]),
+    "srx_filter_init": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(srx_filter)]),
+    "srx_filter_value": (C.c_float, [C.POINTER(srx_filter), C.c_int]),
     "srx_mel_filterbank": (C.c_int, [C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(srx_filter), C.POINTER(C.c_int)]),
     "srx_mfcc_plan_create": (C.c_int, [vp, C.POINTER(srx_mfcc_cfg), C.POINTER(srx_filter), C.c_int, C.POINTER(vp)]),
     "srx_mfcc_plan_destroy": (None, [vp]),
@@ -64,6 +66,8 @@ SIGNATURES = {
     "srx_mfcc_batch_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]),
     "srx_mfcc_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp]),
     "srx_normalize_volume_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_float, vp]),
+    "srx_scale_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "srx_rms_amplitude_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "srx_preemphasis_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, i64, C.c_float]),
     "srx_features_batch_dev": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, i64, vp]),
     "srx_features_batch": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
@@ -78,6 +82,7 @@ SIGNATURES = {
     "srx_hmm_build_training": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "srx_viterbi_batch_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, i64, i64, C.c_float, vp, vp, vp]),
     "srx_train_transitions_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp]),
+    "srx_state_model_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, vp, C.c_int, vp, vp]),
     "srx_em_gather_gid_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, i64, vp]),
     "srx_em_shift_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, i64, vp, vp]),
     "srx_em_pass1_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, i64, vp, vp, vp]),

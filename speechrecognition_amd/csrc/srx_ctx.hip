@@ -153,6 +153,22 @@ float srx_filter_get(const srx_filter &f, int bin) {
     return diff;
 }
 
+// filter::filter(c, w, dft_bins, sps)  src/mfcc.cpp:117-128 and filter::get  src/mfcc.cpp:132-140
+extern "C" int srx_filter_init(float center_hz, float width_hz, int dft_bins, int sps, srx_filter *out) {
+    if (!out || dft_bins <= 0 || sps <= 0) return srx_fail(nullptr, SRX_ERR_INVALID, "srx_filter_init: bad arguments");
+    srx_filter f;
+    f.center = srx_of_map(center_hz, 0, (float)sps, 0, (float)dft_bins);
+    f.width = srx_of_map(width_hz, 0, (float)sps, 0, (float)dft_bins);
+    f.height = 1;
+    float h = 0;
+    for (int b = (int)(f.center - f.width); b <= (int)(f.center + f.width); b++) h += srx_filter_get(f, b);
+    f.height = 1 / h;
+    *out = f;
+    return SRX_OK;
+}
+
+extern "C" float srx_filter_value(const srx_filter *f, int bin) { return f ? srx_filter_get(*f, bin) : 0.0f; }
+
 extern "C" int srx_mel_filterbank(float end, int n, int dft_bins, int sps, srx_filter *out, int *bin_max) {
     if (!out || n <= 0 || dft_bins <= 0 || sps <= 0 || !(end > 0))
         return srx_fail(nullptr, SRX_ERR_INVALID, "srx_mel_filterbank: bad arguments");

@@ -65,6 +65,28 @@ __global__ __launch_bounds__(1024) void k_sumsq_scale(const float *__restrict__ 
     }
 }
 
+// Clip::rmsAmplitude (src/clip.cpp:157-164): sqrt of the f64 sum of f32 squares, one block per utterance.
+__global__ __launch_bounds__(1024) void k_rms(const float *__restrict__ x, const int64_t *__restrict__ soff, double *__restrict__ rms) {
+    const int u = blockIdx.x;
+    const int64_t b = soff[u], e = soff[u + 1];
+    double acc = 0.0;
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        float s = x[i];
+        float sq = s * s;
+        acc += (double)sq;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double part[16];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) part[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += part[i];
+        rms[u] = sqrt(t);
+    }
+}
+
 __global__ void k_apply_scale(float *__restrict__ x, const int64_t *__restrict__ soff, const float *__restrict__ scale) {
     const int u = blockIdx.y;
     const int64_t b = soff[u], e = soff[u + 1];
@@ -431,6 +453,31 @@ extern "C" int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const 
     {
         SrxProf prof_(ctx, "k_apply_scale");
         hipLaunchKernelGGL(k_apply_scale, dim3(64, n_utt), dim3(256), 0, ctx->stream, samples_dev, sample_off_dev, scratch_scale_dev);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+extern "C" int srx_scale_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt, const float *scale_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_scale_dev: null ctx");
+    SRX_REQUIRE(ctx, samples_dev && sample_off_dev && scale_dev && n_utt >= 0, "srx_scale_dev: bad argument");
+    if (n_utt == 0) return SRX_OK;
+    {
+        SrxProf prof_(ctx, "k_apply_scale");
+        hipLaunchKernelGGL(k_apply_scale, dim3(64, n_utt), dim3(256), 0, ctx->stream, samples_dev, sample_off_dev, scale_dev);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+extern "C" int srx_rms_amplitude_dev(srx_ctx *ctx, const float *samples_dev, const int64_t *sample_off_dev, int n_utt,
+                                     double *rms_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_rms_amplitude_dev: null ctx");
+    SRX_REQUIRE(ctx, samples_dev && sample_off_dev && rms_dev && n_utt >= 0, "srx_rms_amplitude_dev: bad argument");
+    if (n_utt == 0) return SRX_OK;
+    {
+        SrxProf prof_(ctx, "k_rms");
+        hipLaunchKernelGGL(k_rms, dim3(n_utt), dim3(1024), 0, ctx->stream, samples_dev, sample_off_dev, rms_dev);
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;

@@ -169,6 +169,46 @@ __global__ __launch_bounds__(256) void k_em_finish(int G, int M, int D, const do
     }
 }
 
+// state_model::augment over every frame of every final path (src/hmm.cpp:46-51, 350-356):
+// probsum[cls] += exp(tr[1]) of the path state (hmm_state::get_adv_prob, src/hmm.cpp:26-28), count[cls] += 1.
+// The reference keeps f32 running sums in path order; here the sums are f64 atomics (order-free).
+__global__ __launch_bounds__(256) void k_state_model(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
+                                                     const int32_t *__restrict__ cls, const float *__restrict__ trlogp,
+                                                     const int32_t *__restrict__ path, const int32_t *__restrict__ status,
+                                                     int64_t total, double *__restrict__ probsum, int32_t *__restrict__ count) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total) return;
+    int lo = 0, hi = n_utt;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (foff[mid] <= f) lo = mid; else hi = mid;
+    }
+    if (status[lo] != 0) return;
+    const int s = soff[lo] + path[f];
+    const int c = cls[s];
+    if (c < 0) return;
+    atomicAdd(&probsum[c], (double)expf(trlogp[(size_t)s * 3 + 1]));
+    atomicAdd(&count[c], 1);
+}
+
+extern "C" int srx_state_model_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *cls_dev, const int32_t *path_dev,
+                                   const int32_t *status_dev, int n_classes, double *probsum_dev, int32_t *count_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_state_model_dev: null ctx");
+    SRX_REQUIRE(ctx, hmm && cls_dev && path_dev && status_dev && probsum_dev && count_dev && n_classes >= 1,
+                "srx_state_model_dev: bad argument");
+    SRX_HIP(ctx, hipMemsetAsync(probsum_dev, 0, (size_t)n_classes * sizeof(double), ctx->stream));
+    SRX_HIP(ctx, hipMemsetAsync(count_dev, 0, (size_t)n_classes * sizeof(int32_t), ctx->stream));
+    if (hmm->n_utt == 0 || hmm->total_frames == 0) return SRX_OK;
+    {
+        SrxProf prof_(ctx, "k_state_model");
+        hipLaunchKernelGGL(k_state_model, dim3((unsigned)ceil_div64(hmm->total_frames, 256)), dim3(256), 0, ctx->stream, hmm->n_utt,
+                           hmm->frame_off_dev, hmm->state_off_dev, cls_dev, hmm->trlogp_dev, path_dev, status_dev,
+                           hmm->total_frames, probsum_dev, count_dev);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
 extern "C" int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev, const int32_t *status_dev,
                                      int64_t total_frames, int32_t *gid_dev) {
     SRX_REQUIRE(nullptr, ctx, "srx_em_gather_gid_dev: null ctx");

@@ -1,0 +1,105 @@
+// Exercises the single-call surface of speechrecognition_amd/host/srx_host.hpp the way the reference's
+// callers use it and prints the results as "key v v v ..." lines; tests/test_gpu_host_cpp.py compares
+// them with the oracle.  Usage: host_api_test <workdir>   (reads <workdir>/in.wav, writes <workdir>/out.mfc)
+#include <cstdio>
+#include <iostream>
+
+#include "../../speechrecognition_amd/host/srx_host.hpp"
+
+using namespace std;
+
+static void dump(const char *key, const float *v, size_t n) {
+    printf("%s", key);
+    for (size_t i = 0; i < n; i++) printf(" %.9g", (double)v[i]);
+    printf("\n");
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) return 2;
+    const string dir = string(argv[1]) + "/";
+    try {
+        // ---- the MFCC block of src/main.cpp:62-92 on one file, call by call ----
+        filterbank fbank = *mel_filterbank(7200, 48, 320, 16000);
+        Clip wav = read_wav(dir + "in.wav");
+        printf("nsamples %d\n", wav.length());
+        printf("rms %.17g\n", wav.rmsAmplitude());
+        wav.normalizeVolume(1);
+        printf("rms_normalized %.17g\n", wav.rmsAmplitude());
+        dump("normalized_head", wav.buf->data(), 16);
+        // one frame through mfcc() before write_features touches the samples
+        Clip frame(wav, 160 * 3, 160 * 3 + 320);
+        float *one = mfcc(frame, fbank, NULL);
+        dump("mfcc_frame3_nopreemph", one, NPARAMS);
+        delete[] one;
+        write_features(wav, 320, 160, fbank, dir + "out.mfc");
+        dump("preemph_head", wav.buf->data(), 16);   // write_features pre-emphasises in place
+        bool threw = false;
+        try {
+            write_features(wav, 320, 160, fbank, dir + "no/such/dir/out.mfc");
+        } catch (int e) {
+            threw = e == 1;
+        }
+        printf("throws_1_on_bad_path %d\n", threw ? 1 : 0);
+        try {
+            read_wav(dir + "missing.wav");
+            printf("missing_wav nothrow\n");
+        } catch (wav_io_exception &e) {
+            printf("missing_wav %s\n", e.what());
+        }
+        vector<featurevec *> fvs = read_features(dir + "out.mfc", 2);
+        printf("nframes %zu\n", fvs.size());
+        dump("feat0", fvs[0]->coeffs, NPARAMS);
+        dump("feat0_delta", fvs[0]->deltas, NPARAMS);
+        dump("feat5_delta2", fvs[5]->delta2s, NPARAMS);
+
+        // ---- acoustic model + training HMM + Viterbi (src/main.cpp:34-36, src/utterance.cpp:20) ----
+        phone::ties acm_ties(phone::ties::NULL_CONTEXT);
+        acoustic_model acm(acm_ties, 1);
+        printf("tied_states %d\n", acm.num_states());
+        phone::ties pc(phone::ties::PHONE_CLASSES), id(phone::ties::IDENT);
+        acoustic_model acm_pc(pc, 1);
+        printf("tied_states_phone_classes %d\n", acm_pc.num_states());
+        // deterministic parameters: mean_g = feature of frame 7g, var = 1 + 0.01 g
+        int g = 0;
+        for (acm_iter it = acm.begin(); it != acm.end(); it++, g++)
+            for (int i = 0; i < FV_LEN; i++) {
+                it->second->gaussians[0].mean[i] = (*fvs[(7 * g) % fvs.size()])[i];
+                it->second->gaussians[0].var[i] = 1.0 + 0.01 * g;
+            }
+        acm.mark_host_dirty();
+        using namespace phone;
+        vector<phone::phone> pron = {SIL, HH, AH, L, OW, SIL, W, ER, L, D, SIL};
+        hmm h(pron, &acm);
+        printf("nstates %zu\n", h.states.size());
+        printf("ntr");
+        for (hmm_state &s : h.states) printf(" %zu", s.tr.size());
+        printf("\n");
+        float e = acm(*fvs[3], h.states[2].ctx);
+        printf("score_f3_s2 %.9g\n", (double)e);
+        float prevp = 0;
+        path p = h.viterbi(fvs, prevp, 1e10);
+        printf("prevp %.9g\n", (double)prevp);
+        printf("path");
+        for (hmm_state *s : p) printf(" %d", h.indexOf(s));
+        printf("\n");
+        h.train_transition_probabilities(p);
+        printf("tr");
+        for (hmm_state &s : h.states)
+            for (transition &t : s.tr) printf(" %.9g", (double)t.second);
+        printf("\n");
+        vector<utterance> uts;
+        uts.push_back(utterance("hello world", pron, fvs, acm));
+        featurevec mu = mean(uts);
+        featurevec var = variance(uts, mu);
+        dump("corpus_mean", mu.coeffs, FV_LEN);
+        dump("corpus_var", var.coeffs, FV_LEN);
+        vector<featurevec *> few(fvs.begin(), fvs.begin() + 4);
+        path none = h.viterbi(few, prevp, 1e10);   // 4 frames cannot reach state 10
+        printf("no_path_len %zu\n", none.size());
+        delete wav.buf;
+    } catch (srx_error &e) {
+        printf("srx_error %d %s\n", e.code, e.what());
+        return 3;
+    }
+    return 0;
+}

@@ -1,0 +1,233 @@
+"""The C++ host layer (speechrecognition_amd/host: the reference's class surface over the C ABI) and the
+headless driver `srx` (run-time-flag equivalent of src/main.cpp:25-92), run as the reference's callers would
+run them and checked against the oracle.  Binaries are prebuilt by __graft_entry__.build() (make -C
+speechrecognition_amd/host); nothing is compiled here."""
+import os
+import struct
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+from speechrecognition_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "speechrecognition_amd", "lib")
+SRX = os.path.join(LIB, "srx")
+API_TEST = os.path.join(LIB, "srx_host_api_test")
+
+PHONE_NAMES = ["SIL", "AA", "AE", "AH", "AO", "AW", "AY", "B", "CH", "D", "DH", "EH", "ER", "EY", "F", "G", "HH", "IH", "IY",
+               "JH", "K", "L", "M", "N", "NG", "OW", "OY", "P", "R", "S", "SH", "T", "TH", "UH", "UW", "V", "W", "Y", "Z", "ZH"]
+
+
+def _write_wav(path, x, channels=1, bits=16):
+    """x float in [-1,1] (mono) -> PCM file; returns the samples as read_wav (src/wav.cpp:36-53) will see them."""
+    with wave.open(path, "wb") as w:
+        w.setnchannels(channels)
+        w.setsampwidth(bits // 8)
+        w.setframerate(16000)
+        if bits == 16:
+            q = np.round(x * 32767).astype(np.int16)
+            if channels == 2:
+                r = np.roll(q, 7)
+                w.writeframes(np.stack([q, r], axis=1).tobytes())
+                return ((q.astype(np.float32) / np.float32(32768)) + (r.astype(np.float32) / np.float32(32768))) / np.float32(2)
+            w.writeframes(q.tobytes())
+            return q.astype(np.float32) / np.float32(32768)
+        q = np.round((x / 2 + 0.5) * 255).astype(np.uint8)
+        w.writeframes(q.tobytes())
+        return q.astype(np.float32) / np.float32(255)
+
+
+def _read_mfc(path):
+    raw = open(path, "rb").read()
+    n = struct.unpack("<i", raw[:4])[0]
+    c = np.frombuffer(raw[4:], np.float32).reshape(n, 13)
+    return c
+
+
+def _frame_rel_err(got, ref):
+    scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-30)
+    return (np.abs(got - ref) / scale).max()
+
+
+def _run(cmd, env_extra=None, cwd=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=cwd, timeout=110)
+    assert r.returncode == 0, (cmd, r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return r.stdout
+
+
+def _kv(out):
+    d = {}
+    for ln in out.splitlines():
+        parts = ln.split()
+        if parts:
+            d[parts[0]] = parts[1:]
+    return d
+
+
+def test_host_api_calls_match_oracle(oracle, tmp_path):
+    assert os.path.exists(API_TEST), "run __graft_entry__.build() first"
+    x = synth.utterance_audio(21, 16000)
+    samples = _write_wav(str(tmp_path / "in.wav"), x)
+    d = _kv(_run([API_TEST, str(tmp_path)], {"SRX_SCORE_PATH": "exact"}))
+    f = lambda k: np.array([float(v) for v in d[k]])
+    assert int(d["nsamples"][0]) == 16000
+    rms = oracle.lib().orc_rms_amplitude(samples, len(samples))
+    assert abs(f("rms")[0] - rms) <= 1e-10 * rms
+    xn = oracle.normalize_volume(samples)
+    assert abs(f("rms_normalized")[0] - 1.0) < 1e-6
+    np.testing.assert_allclose(f("normalized_head"), xn[:16], rtol=3e-7)
+    fb, _ = oracle.mel_filterbank(7200, 48, 320, 16000)
+    one = np.zeros(13, np.float32)
+    oracle.lib().orc_mfcc_frame(np.ascontiguousarray(xn[480:800]), 320, fb.ctypes.data, 48, 13, one, None)
+    assert np.abs(f("mfcc_frame3_nopreemph") - one).max() <= 1e-4 * np.abs(one).max()
+    ref_ceps, xpre = oracle.write_features(xn, 320, 160, fb, 13)
+    np.testing.assert_allclose(f("preemph_head"), xpre[:16], rtol=2e-6, atol=1e-9)
+    got = _read_mfc(str(tmp_path / "out.mfc"))
+    assert got.shape == ref_ceps.shape and _frame_rel_err(got, ref_ceps) <= 1e-4
+    assert d["throws_1_on_bad_path"] == ["1"]
+    assert " ".join(d["missing_wav"]) == "Could not open WAV file"
+    feats = oracle.read_features(got, 2)       # smoothing + deltas are bit-exact given the same cepstra
+    assert int(d["nframes"][0]) == len(feats)
+    np.testing.assert_allclose(f("feat0"), feats[0, :13], rtol=1e-7)
+    np.testing.assert_allclose(f("feat0_delta"), feats[0, 13:26], rtol=1e-7)
+    np.testing.assert_allclose(f("feat5_delta2"), feats[5, 26:], rtol=1e-6, atol=1e-9)
+    assert d["tied_states"] == ["40"] and d["tied_states_phone_classes"] == ["4000"]
+    assert d["nstates"] == ["11"] and d["ntr"] == "2 2 2 2 3 2 2 2 2 2 1".split()
+    # model: state g (= phone id under NULL_CONTEXT ties) has mean = feats[7g % n], var = 1 + 0.01 g
+    n = len(feats)
+    mean = np.stack([feats[(7 * g) % n, :13] for g in range(40)]).astype(np.float64)[:, None, :]
+    var = np.stack([np.full(13, 1.0 + 0.01 * g) for g in range(40)])[:, None, :]
+    lw = np.zeros((40, 1), np.float32)
+    emis = oracle.gmm_score(feats, mean, var, lw, 13, 0)
+    ph = np.array([0, 16, 3, 21, 25, 0, 36, 12, 21, 9, 0], np.int32)
+    assert abs(f("score_f3_s2")[0] - emis[3, ph[2]]) <= 1e-6 * max(1, abs(emis[3, ph[2]]))
+    ntr, tr, _ = oracle.build_training_hmm(ph)
+    r = oracle.viterbi(emis, ph, ntr, tr)
+    assert r["status"] == 0
+    assert [int(v) for v in d["path"]] == list(r["path"])
+    assert abs(f("prevp")[0] - r["prevp"]) <= 1e-6 * abs(r["prevp"])
+    tr2 = oracle.train_transitions(r["path"], ntr, tr)
+    want = np.concatenate([tr2[s, :ntr[s]] for s in range(11)])
+    np.testing.assert_allclose(f("tr"), want, rtol=3e-6, atol=1e-7)
+    assert d["no_path_len"] == ["0"]
+    mu, var = oracle.corpus_mean_var(feats, 13)   # reference: f32 running sums; device: f64 sums
+    np.testing.assert_allclose(f("corpus_mean"), mu, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(f("corpus_var"), var, rtol=1e-4)
+
+
+def _make_corpus(root, rng):
+    """A Voxforge-shaped tree (README:26-39): _list / _train, <folder>etc/PROMPTS, wav/, mfc/."""
+    folders = ["spk1-20260101-aaa/", "spk2-20260102-bbb/"]
+    samples = {}
+    for fi, fo in enumerate(folders):
+        for sub in ("etc", "wav", "mfc"):
+            os.makedirs(os.path.join(root, fo, sub))
+        lines = []
+        for k in range(3):
+            name = "a%02d%d" % (fi, k)
+            L = int(rng.integers(12000, 30000))
+            x = synth.utterance_audio(100 * fi + k, L)
+            kind = (fi * 3 + k) % 3
+            samples[(fo, name)] = _write_wav(os.path.join(root, fo, "wav", name + ".wav"), x,
+                                             channels=2 if kind == 1 else 1, bits=8 if kind == 2 else 16)
+            lines.append("%s/mfc/%s SOME WORDS HERE" % (fo.rstrip("/"), name))
+        open(os.path.join(root, fo, "etc", "PROMPTS"), "w").write("\n".join(lines) + "\n")
+    for lst in ("_list", "_train"):
+        open(os.path.join(root, lst), "w").write("\n".join(folders) + "\n")
+    return folders, samples
+
+
+def test_headless_driver_mfcc_train_align(oracle, tmp_path):
+    assert os.path.exists(SRX), "run __graft_entry__.build() first"
+    rng = np.random.default_rng(3)
+    root = str(tmp_path / "vox") + "/"
+    os.makedirs(root)
+    folders, samples = _make_corpus(root, rng)
+    out = _run([SRX, "--mode", "mfcc", "--voxforge", root, "--batch", "4"])
+    assert "wrote features for 6 of 6" in out
+    fb, _ = oracle.mel_filterbank(7200, 48, 320, 16000)
+    ceps = {}
+    for (fo, name), x in samples.items():
+        got = _read_mfc(os.path.join(root, fo, "mfc", name))
+        ref, _ = oracle.write_features(oracle.normalize_volume(x), 320, 160, fb, 13)
+        assert got.shape == ref.shape, (fo, name)
+        assert _frame_rel_err(got, ref) <= 1e-4, (fo, name)
+        ceps[(fo, name)] = got
+    # ---- TRAIN mode: phone strings stand in for the text front end ----
+    keys = sorted(ceps)
+    phones = {}
+    for fo in folders:
+        lines = []
+        for (f2, name) in keys:
+            if f2 != fo:
+                continue
+            ph = synth.phone_string(rng, n_words=3)
+            phones[(f2, name)] = ph
+            lines.append("%smfc/%s %s" % (fo, name, " ".join(PHONE_NAMES[p] for p in ph)))
+        open(os.path.join(root, fo, "etc", "PHONES"), "w").write("\n".join(lines) + "\n")
+    order = [k for fo in folders for k in keys if k[0] == fo]
+    feats = [oracle.read_features(ceps[k], 2) for k in order]
+    allf = np.concatenate(feats)
+    G, D = 40, 13
+    mu, sd = allf[:, :D].mean(0), allf[:, :D].std(0)
+    mean0 = (mu + sd * rng.standard_normal((G, 1, D)) * 0.7).astype(np.float64)
+    var0 = (sd ** 2 * rng.uniform(0.8, 1.2, (G, 1, D))).astype(np.float64)
+    w0 = np.ones((G, 1), np.float32)
+    with open(root + "init.txt", "w") as f:
+        f.write("srx-model %d 1 %d\n" % (G, D))
+        for g in range(G):
+            f.write("state 0 %d 0\nw 1\nmean %s\nvar %s\n" % (g, " ".join(repr(float(v)) for v in mean0[g, 0]),
+                                                           " ".join(repr(float(v)) for v in var0[g, 0])))
+    iters = 3
+    env = {"SRX_SCORE_PATH": "exact"}
+    _run([SRX, "--mode", "train", "--voxforge", root, "--iters", str(iters), "--model", root + "init.txt", "--out",
+          root + "trained.txt"], env)
+    # ---- the same three iterations with the oracle, including the acm / temp_acm ping-pong:
+    # the utterance HMMs keep pointing at object O while the trainer swaps (acm, temp_acm) = (O, C), (C, O), ...
+    O = [mean0.copy(), var0.copy(), w0.copy()]
+    Cm = [mean0.copy(), var0.copy(), w0.copy()]
+    acm, temp = O, Cm
+    hmms = [list(oracle.build_training_hmm(phones[k])[:2]) for k in order]
+    gidx = [phones[k].astype(np.int32) for k in order]      # tied index = phone id under NULL_CONTEXT ties
+    for _ in range(iters):
+        gids = []
+        for u, fv in enumerate(feats):
+            e = oracle.gmm_score(fv, O[0], O[1], oracle.set_wt(O[2]), D, 0)
+            r = oracle.viterbi(e, gidx[u], hmms[u][0], hmms[u][1])
+            assert r["status"] == 0
+            hmms[u][1] = oracle.train_transitions(r["path"], hmms[u][0], hmms[u][1])
+            gids.append(gidx[u][r["path"]])
+        Bm, Bv, Bw, _, _ = oracle.em_statistics(allf, np.concatenate(gids), D, acm[0], acm[1], acm[2], 0.2)
+        temp[0][...] = np.asarray(Bm, np.float64)
+        temp[1][...] = np.asarray(Bv, np.float64)
+        temp[2][...] = Bw
+        acm, temp = temp, acm
+    got = open(root + "trained.txt").read().split("\n")
+    gm = np.array([[float(v) for v in ln.split()[1:]] for ln in got if ln.startswith("mean")])
+    gv = np.array([[float(v) for v in ln.split()[1:]] for ln in got if ln.startswith("var")])
+    rm, rv = acm[0][:, 0, :], acm[1][:, 0, :]
+    assert np.array_equal(np.isnan(gm), np.isnan(rm))
+    ok = ~np.isnan(rm)
+    assert ok.sum() > 13 * 10
+    np.testing.assert_allclose(gm[ok], rm[ok], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gv[ok], rv[ok], rtol=1e-7, atol=1e-9)
+    # mean/variance initialisation path (src/main.cpp:52-54; random jitter, so only that it runs and writes a model)
+    _run([SRX, "--mode", "train", "--voxforge", root, "--iters", "1", "--out", root + "rand.txt"], env)
+    assert open(root + "rand.txt").readline().split() == ["srx-model", "40", "1", "13"]
+    # ---- ALIGN mode under the initial model ----
+    out = _run([SRX, "--mode", "align", "--voxforge", root, "--model", root + "init.txt"], env)
+    rows = [ln.split() for ln in out.splitlines() if ln and ln[0].isdigit()]
+    assert len(rows) == len(order)
+    for u, row in enumerate(rows):
+        e = oracle.gmm_score(feats[u], mean0, var0, oracle.set_wt(w0), D, 0)
+        ntr, tr, _ = oracle.build_training_hmm(phones[order[u]])
+        r = oracle.viterbi(e, gidx[u], ntr, tr)
+        assert [int(v) for v in row[2:]] == list(r["path"]), u
+        assert abs(float(row[1]) - r["prevp"]) <= 1e-6 * abs(r["prevp"])
