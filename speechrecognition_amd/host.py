@@ -77,6 +77,20 @@ class DevArray:
         check(ctx.lib.srx_malloc(ctx.h, self.nbytes, C.byref(p)), ctx.h)
         self.ptr = p
 
+    @classmethod
+    def wrap(cls, ctx, ptr, shape, dtype, owner=None):
+        """A non-owning view of device memory allocated elsewhere (e.g. a torch tensor: pass it as `owner`
+        to keep it alive)."""
+        a = cls.__new__(cls)
+        a.ctx = ctx
+        a.shape = (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(v) for v in shape)
+        a.dtype = np.dtype(dtype)
+        a.nbytes = int(np.prod(a.shape, dtype=np.int64)) * a.dtype.itemsize
+        a.ptr = C.c_void_p(int(ptr))
+        a.owner = owner
+        a.borrowed = True
+        return a
+
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=self.dtype)
         assert host.nbytes == self.nbytes, (host.shape, self.shape)
@@ -88,6 +102,10 @@ class DevArray:
         return out
 
     def free(self):
+        if getattr(self, "borrowed", False):
+            self.ptr = None
+            self.owner = None
+            return
         if self.ptr and self.ctx.h:
             self.ctx.lib.srx_free(self.ctx.h, self.ptr)
         self.ptr = None
@@ -285,6 +303,9 @@ class HmmBatch:
 
     def trlogp(self):
         return self.trlogp_d.get()
+
+    def c_ref(self):
+        return C.byref(self.c)
 
     def viterbi(self, emis_d, stride_t, stride_g=1, beam=1e10, path_d=None, final_d=None, status_d=None):
         """hmm::viterbi for every utterance (src/hmm.cpp:150-224); emission (t, col) at

@@ -1,0 +1,114 @@
+"""Multi-GPU layer: one process per GPU, utterances sharded across ranks, sufficient statistics combined
+with all-reduce (RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" for CPU tests).
+
+The reference is single-process; what shards are its sequential `for i < ut.size()` loops (src/hmm.cpp:258,
+269, 275, 298, 319; src/main.cpp:70-91).  MFCC, scoring and alignment need no communication.  One EM iteration
+exchanges:
+    1. MAX  of shift[G*M]  f32   (per-component log-density maximum: makes every rank use the same shift)
+    2. SUM  of stats1[G*M*(1+D)] f64   (zeta sums and zeta*x sums)   -> weights and means, identically on every rank
+    3. SUM  of stats2[G*M*D] f64       (zeta*(x - new mean)^2 sums)  -> variances, blend
+and once after the last iteration the state-model (probsum, count) tables (src/hmm.cpp:350-356).
+"""
+import numpy as np
+
+
+def shard_utterances(costs, world):
+    """Greedy longest-processing-time partition: utterances sorted by cost (frames x states) descending, each
+    given to the currently lightest rank.  Returns a list of index arrays (ascending within a rank).
+    Deterministic; every rank computes the same partition from the same costs."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world)
+    parts = [[] for _ in range(world)]
+    for u in order:
+        r = int(np.argmin(load))          # ties -> lowest rank
+        parts[r].append(int(u))
+        load[r] += costs[u]
+    return [np.array(sorted(p), dtype=np.int64) for p in parts]
+
+
+class Exchange:
+    """The collectives of one EM iteration over torch tensors (CUDA tensors under nccl = RCCL, CPU tensors under
+    gloo).  world == 1 (or no process group) is a no-op, so the single-GPU path runs the same code."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.bytes_reduced = 0
+
+    def allreduce_max(self, t):
+        if self.active:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+            self.bytes_reduced += t.numel() * t.element_size()
+        return t
+
+    def allreduce_sum(self, t):
+        if self.active:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.bytes_reduced += t.numel() * t.element_size()
+        return t
+
+
+class TrainingShard:
+    """One rank's share of an embedded-training corpus, resident on its GPU, and the iteration of
+    hmm::train (src/hmm.cpp:254-347) over it.  Buffers that are exchanged are torch tensors (so that
+    torch.distributed can reduce them in place); libsrx reads and writes them through their data pointers."""
+
+    def __init__(self, ctx, hmm_batch, feats_d, ld, G, M, D, exchange=None, mix_mode=0, score_path=0):
+        import torch
+        from . import host
+        self.torch, self.host = torch, host
+        self.ctx, self.hb, self.feats_d, self.ld = ctx, hmm_batch, feats_d, ld
+        self.G, self.M, self.D = G, M, D
+        self.ex = exchange or Exchange()
+        self.mix_mode, self.score_path = mix_mode, score_path
+        T = hmm_batch.total_frames
+        self.T = T
+        dev = torch.device("cuda", ctx.device)
+        self.emis = ctx.empty((G, max(T, 1)), np.float32)          # state-major [G][T]
+        self.path = ctx.zeros((max(T, 1),), np.int32)
+        self.final = ctx.zeros((max(hmm_batch.n_utt, 1),), np.float32)
+        self.status = ctx.zeros((max(hmm_batch.n_utt, 1),), np.int32)
+        self.gid = ctx.empty((max(T, 1),), np.int32)
+        self.logp = ctx.empty((max(T * M, 1),), np.float32)
+        self.t_shift = torch.empty(G * M, dtype=torch.float32, device=dev)
+        self.t_stats1 = torch.empty(G * M * (1 + D), dtype=torch.float64, device=dev)
+        self.t_stats2 = torch.empty(G * M * D, dtype=torch.float64, device=dev)
+        self.shift = host.DevArray.wrap(ctx, self.t_shift.data_ptr(), (G * M,), np.float32, self.t_shift)
+        self.stats1 = host.DevArray.wrap(ctx, self.t_stats1.data_ptr(), (G * M * (1 + D),), np.float64, self.t_stats1)
+        self.stats2 = host.DevArray.wrap(ctx, self.t_stats2.data_ptr(), (G * M * D,), np.float64, self.t_stats2)
+
+    def _collective(self, fn, t):
+        """libsrx launches on the context's stream, torch.distributed orders the collective after torch's
+        current stream: bracket the exchange with host-side waits on both (three per iteration; the
+        reduced buffers are <= 10 MB, SURVEY.md 8e, so the exchange itself is short)."""
+        if not self.ex.active:
+            return
+        self.ctx.sync()
+        fn(t)
+        if t.is_cuda:
+            self.torch.cuda.current_stream(t.device).synchronize()
+
+    def iteration(self, vit_model, A, B, keep=0.2):
+        """align under `vit_model`, re-estimate transitions, rebuild B from statistics under A (all ranks end
+        with identical B).  The caller swaps (A, B) like src/hmm.cpp:344-346."""
+        from ._capi import check
+        ctx, hb, lib = self.ctx, self.hb, self.ctx.lib
+        T = self.T
+        if T > 0:
+            vit_model.score_dev(self.feats_d, self.ld, T, self.emis, 1, T, self.mix_mode, self.score_path)
+            hb.viterbi(self.emis, 1, T, 1e10, self.path, self.final, self.status)
+            hb.train_transition_probabilities(self.path, self.status)
+            check(lib.srx_em_gather_gid_dev(ctx.h, hb.c_ref(), self.path.ptr, self.status.ptr, T, self.gid.ptr), ctx.h)
+        check(lib.srx_em_shift_dev(ctx.h, A.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr, self.shift.ptr), ctx.h)
+        self._collective(self.ex.allreduce_max, self.t_shift)
+        check(lib.srx_em_pass1_dev(ctx.h, A.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr, self.shift.ptr,
+                                   self.stats1.ptr), ctx.h)
+        self._collective(self.ex.allreduce_sum, self.t_stats1)
+        check(lib.srx_em_means_dev(ctx.h, B.h, self.stats1.ptr, self.shift.ptr), ctx.h)
+        check(lib.srx_em_pass2_dev(ctx.h, A.h, B.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr,
+                                   self.shift.ptr, self.stats2.ptr), ctx.h)
+        self._collective(self.ex.allreduce_sum, self.t_stats2)
+        check(lib.srx_em_finish_dev(ctx.h, A.h, B.h, self.stats1.ptr, self.stats2.ptr, keep), ctx.h)

@@ -1,0 +1,74 @@
+"""Two ranks (gloo, both on cuda:0) run parallel.TrainingShard.iteration -- alignment, transition re-estimation,
+statistics through libsrx, the three exchanges -- for two iterations with the acm / temp_acm ping-pong, and must
+end with the single-process result of the oracle (src/hmm.cpp:254-347).  RCCL itself needs one GPU per rank and is
+exercised by the driver's multi-GPU bench; the collective calls are the same torch.distributed.all_reduce."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import synth
+from tests.test_parallel_cpu import run_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,mix_mode", [(1, 0), (2, 1)])
+def test_training_iteration_world2_matches_single_process_oracle(oracle, tmp_path, M, mix_mode):
+    rng = np.random.default_rng(21 + M)
+    G, D, iters = 40, 13, 2
+    n_utt = 7
+    phones = [synth.phone_string(rng, n_words=3) for _ in range(n_utt)]
+    lens = rng.integers(120, 300, n_utt)
+    frame_off = np.zeros(n_utt + 1, np.int64)
+    frame_off[1:] = np.cumsum(lens)
+    T = int(frame_off[-1])
+    mean, var, w = synth.random_model(G, M, D, 9)
+    var *= 2.0
+    feats = np.zeros((T, 39), np.float32)
+    for u in range(n_utt):   # frames drawn around the utterance's own phone sequence so that alignments are non-trivial
+        seg = np.sort(rng.integers(0, len(phones[u]), lens[u]))
+        g = phones[u][seg]
+        feats[frame_off[u]:frame_off[u + 1], :D] = (mean[g, 0] + rng.standard_normal((lens[u], D)) * 1.2).astype(np.float32)
+    np.savez(tmp_path / "in.npz", shape=[G, M, D], mean=mean, var=var, w=w, feats=feats, frame_off=frame_off, iters=iters,
+             mix_mode=mix_mode, **{"ph%d" % u: phones[u] for u in range(n_utt)})
+    outs = run_world("gpu", tmp_path, 2)
+    assert sorted(np.concatenate([o["mine"] for o in outs]).tolist()) == list(range(n_utt))
+    assert all(len(o["mine"]) > 0 for o in outs)
+    # ---- single-process oracle ----
+    O = [mean.copy(), var.copy(), w.copy()]
+    Cm = [mean.copy(), var.copy(), w.copy()]
+    A, B = O, Cm
+    hm = [list(oracle.build_training_hmm(p)[:2]) for p in phones]
+    paths = [None] * n_utt
+    for _ in range(iters):
+        gids = []
+        for u in range(n_utt):
+            fv = feats[frame_off[u]:frame_off[u + 1]]
+            e = oracle.gmm_score(fv, O[0], O[1], oracle.set_wt(O[2]), D, mix_mode)
+            r = oracle.viterbi(e, phones[u].astype(np.int32), hm[u][0], hm[u][1])
+            assert r["status"] == 0
+            paths[u] = r["path"]
+            hm[u][1] = oracle.train_transitions(r["path"], hm[u][0], hm[u][1])
+            gids.append(phones[u][r["path"]].astype(np.int32))
+        Bm, Bv, Bw, _, _ = oracle.em_statistics(feats, np.concatenate(gids), D, A[0], A[1], A[2], 0.2)
+        B[0][...], B[1][...], B[2][...] = np.asarray(Bm, np.float64), np.asarray(Bv, np.float64), Bw
+        A, B = B, A
+    rm, rv, rw = A
+    for o in outs:
+        assert np.array_equal(np.isnan(o["mean"]), np.isnan(rm))
+        ok = ~np.isnan(rm)
+        # after the first iteration the models differ in the last bits (f64 vs 80-bit accumulation), which can move an
+        # f32 log-density of the second iteration by one ulp and with it one frame's zeta by ~1e-6 relative
+        np.testing.assert_allclose(o["mean"][ok], rm[ok], rtol=1e-6, atol=2e-7)
+        np.testing.assert_allclose(o["var"][ok], rv[ok], rtol=1e-6, atol=2e-7)
+        okw = ~np.isnan(rw)
+        np.testing.assert_allclose(o["w"][okw], rw[okw], rtol=1e-6)
+        assert int(o["bytes_reduced"]) == iters * (G * M * 4 + G * M * (1 + D) * 8 + G * M * D * 8)
+        # this rank's last alignments and transition log-probs equal the single-process ones
+        got_path, got_tr = o["path"], o["trlogp"]
+        pos = spos = 0
+        for u in o["mine"]:
+            n, S = len(paths[u]), len(phones[u])
+            assert np.array_equal(got_path[pos:pos + n], paths[u]), u
+            np.testing.assert_allclose(got_tr[spos:spos + S], hm[u][1], rtol=5e-6, atol=1e-7)
+            pos, spos = pos + n, spos + S
+    assert outs[0]["mean"].tobytes() == outs[1]["mean"].tobytes()   # identical on every rank
