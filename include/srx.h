@@ -159,8 +159,11 @@ int srx_model_get(srx_model *m, double *mean, double *var, float *weight);
 int srx_model_copy(srx_model *dst, const srx_model *src); /* acoustic_model(acoustic_model*) src/gmm.cpp:171-175 */
 
 typedef enum {
-    SRX_SCORE_MFMA = 0,  /* f32 MFMA contraction over [x^2, x, 1] (fast path) */
-    SRX_SCORE_EXACT = 1  /* per-dimension evaluation in the reference's operation order (f64 for long double) */
+    SRX_SCORE_MFMA = 0,       /* f32-input MFMA contraction over [x^2, x, 1] (exact f32 products) */
+    SRX_SCORE_EXACT = 1,      /* per-dimension evaluation in the reference's operation order (f64 for long double) */
+    SRX_SCORE_MFMA_F16X3 = 2  /* the same contraction on f16 MFMA with both operands split hi + lo (three products,
+                                 f32 accumulate: ~22 significant bits per product); D <= 39, M <= 16; frames or
+                                 models outside the f16 range are re-evaluated / routed to SRX_SCORE_MFMA */
 } srx_score_path;
 
 /* acoustic_model::operator()(fv, ctx) for every frame and every tied state

@@ -17,6 +17,7 @@ SRX_MIX_COMPONENT0 = 0
 SRX_MIX_LOGSUMEXP = 1
 SRX_SCORE_MFMA = 0
 SRX_SCORE_EXACT = 1
+SRX_SCORE_MFMA_F16X3 = 2
 
 
 class SrxError(RuntimeError):

@@ -101,6 +101,31 @@ struct srx_model {
     float *packed = nullptr;   // see srx_gmm.hip
     float *center = nullptr;   // [D] centring vector (f32)
     int packed_mode = -1;      // mix mode the packing was built for
-    bool dirty = true;
+    // every change of the parameters bumps `version`; each packed form remembers the version it was built from
+    uint64_t version = 1;
+    uint64_t packed_version = 0;
     size_t packed_bytes = 0;
+    // split-f16 operand of the SRX_SCORE_MFMA_F16X3 path (srx_gmm_f16.hip)
+    void *packed16 = nullptr;      // [row tile][k-step][lane][8 halves], hi segments then lo segments
+    size_t packed16_bytes = 0;
+    uint64_t packed16_version = 0;
+    int packed16_mode = -1;
+    float *colstats = nullptr;     // [3][D]: centre, column scale s_d, 1/s_d
+    int *flag16 = nullptr;         // device flag: some coefficient does not fit f16
+    bool f16_ok = false;
 };
+
+// gaussian::operator()  src/gmm.cpp:41-49 in the reference's operation order (f64 stands in for long double)
+__device__ __forceinline__ float srx_logprob_exact(const float *__restrict__ fv, const double *__restrict__ mean,
+                                                   const double *__restrict__ var, float logwt, int D) {
+    float res = 0.0f;
+    const float l2pi = (float)-0.4515827052894549;  // (float)log(M_2_PI), src/gmm.cpp:43
+    for (int i = 0; i < D; i++) {
+        float t = (float)((double)fv[i] - mean[i]);
+        float tt = t * t;
+        double term = ((double)l2pi + log(var[i])) + (double)tt / var[i];
+        res = (float)((double)res + term);
+    }
+    float h = -0.5f * res;
+    return h + logwt;
+}

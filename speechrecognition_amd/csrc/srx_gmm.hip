@@ -48,6 +48,9 @@ extern "C" void srx_model_destroy(srx_model *m) {
     (void)hipFree(m->logwt);
     (void)hipFree(m->center);
     (void)hipFree(m->packed);
+    (void)hipFree(m->packed16);
+    (void)hipFree(m->colstats);
+    (void)hipFree(m->flag16);
     delete m;
 }
 
@@ -64,7 +67,7 @@ extern "C" int srx_model_set(srx_model *m, const double *mean, const double *var
     for (size_t i = 0; i < n; i++) lw[i] = logf(weight[i]);
     SRX_HIP(ctx, hipMemcpyAsync(m->logwt, lw.data(), n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    m->dirty = true;
+    m->version++;
     return SRX_OK;
 }
 
@@ -88,27 +91,13 @@ extern "C" int srx_model_copy(srx_model *dst, const srx_model *src) {
     SRX_HIP(ctx, hipMemcpyAsync(dst->var, src->var, n * dst->D * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     SRX_HIP(ctx, hipMemcpyAsync(dst->weight, src->weight, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     SRX_HIP(ctx, hipMemcpyAsync(dst->logwt, src->logwt, n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-    dst->dirty = true;
+    dst->version++;
     return SRX_OK;
 }
 
 // ------------------------------------------------------------------------------------------
 // EXACT path: gaussian::operator() in the reference's order (src/gmm.cpp:41-49).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gaussian_logprob_exact(const float *__restrict__ fv, const double *__restrict__ mean,
-                                                        const double *__restrict__ var, float logwt, int D) {
-    float res = 0.0f;
-    const float l2pi = (float)-0.4515827052894549;  // (float)log(M_2_PI), src/gmm.cpp:43
-    for (int i = 0; i < D; i++) {
-        float t = (float)((double)fv[i] - mean[i]);
-        float tt = t * t;
-        double term = ((double)l2pi + log(var[i])) + (double)tt / var[i];
-        res = (float)((double)res + term);
-    }
-    float h = -0.5f * res;
-    return h + logwt;
-}
-
 __global__ __launch_bounds__(256) void k_gmm_exact(const float *__restrict__ feats, int ld, int64_t T, int G, int M, int D,
                                                    const double *__restrict__ mean, const double *__restrict__ var,
                                                    const float *__restrict__ logwt, int mode, float *__restrict__ out,
@@ -121,19 +110,21 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float *__restrict__ fea
     float r;
     if (mode == SRX_MIX_COMPONENT0) {
         const size_t o = (size_t)g * M;
-        r = gaussian_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D);
+        r = srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D);
     } else {
         double s = 0.0;
         for (int m = 0; m < M; m++) {
             const size_t o = (size_t)g * M + m;
-            s += exp((double)gaussian_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D));
+            s += exp((double)srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D));
         }
         r = (float)log(s);
     }
     out[t * st_t + (int64_t)g * st_g] = r;
 }
 
-// MFMA path: srx_gmm_mfma.hip
+// MFMA paths: srx_gmm_mfma.hip (f32 inputs), srx_gmm_f16.hip (split-f16 inputs)
+int srx_gmm_score_f16x3(srx_ctx *ctx, srx_model *m, int mix_mode, const float *feats, int ld, int64_t T, float *out, int64_t st_t,
+                        int64_t st_g);
 int srx_gmm_score_mfma(srx_ctx *ctx, srx_model *m, int mix_mode, const float *feats, int ld, int64_t T, float *out, int64_t st_t,
                        int64_t st_g);
 
@@ -157,6 +148,8 @@ extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int s
         SRX_LAUNCH_CHECK(ctx);
         return SRX_OK;
     }
+    if (score_path == SRX_SCORE_MFMA_F16X3)
+        return srx_gmm_score_f16x3(ctx, m, mix_mode, feats_dev, ld, T, out_dev, stride_t, stride_g);
     SRX_REQUIRE(ctx, score_path == SRX_SCORE_MFMA, "srx_gmm_score_dev: bad score_path");
     return srx_gmm_score_mfma(ctx, m, mix_mode, feats_dev, ld, T, out_dev, stride_t, stride_g);
 }

@@ -1,0 +1,451 @@
+// GMM emission scoring on the f16 matrix cores with split operands (SRX_SCORE_MFMA_F16X3).
+//
+// Same contraction as srx_gmm_mfma.hip -- replaces gaussian::operator() (src/gmm.cpp:41-49), gmm::operator()
+// (src/gmm.cpp:99-109) and acoustic_model::operator() (src/gmm.cpp:184-186) for all frames x all tied states:
+//   logp_{g,m}(x) = const_{g,m} + sum_d [ (-s_d^2/(2 var_d)) (x'_d/s_d)^2 + (s_d mu'_d/var_d) (x'_d/s_d) ],  x' = x - c, mu' = mu - c
+// i.e. [Gaussians x K] . [K x frames] with K = 2D+1 <= 80 -- but on v_mfma_f32_32x32x16_f16, 16x the rate of the
+// f32-input MFMA.  f16 alone (11 significant bits) cannot hold the 1e-4 bar, so both operands are split
+//   a = a_hi + a_lo,  b = b_hi + b_lo   (a_hi = f16(a), a_lo = f16(a - a_hi); f16 subnormals are honoured by the MFMA)
+// and three products are accumulated in f32:  a_lo b_hi + a_hi b_lo + a_hi b_hi.  The dropped a_lo b_lo term and the
+// rounding of the lo parts are ~2^-22 relative per product (measured against f64: <= 2e-6 of max(|logp|, 1)).
+// c centres the data (mean of all component means); s_d is a power of two per dimension (span of the model / 8), so
+// that the frame operand is O(1..30) where the model lives: exact to apply, keeps the lo parts out of the subnormal
+// range and squares far from 65504.
+//
+// What does not fit is handled explicitly, never silently:
+//   * a model coefficient beyond the f16 range (variance below ~1e-5 of the span^2): k_pack16 raises a flag, the
+//     host reads it when the model changes, and scoring goes to the f32-input path (srx_gmm_mfma.hip);
+//   * a frame further than ~30 spans from the centre, or NaN: k_prep16 flags the frame, k_gmm_fixup16 re-evaluates its
+//     row with the exact per-dimension formula.
+//
+// Data movement.  Both operands are stored in MFMA fragment order, one 16-byte piece per lane:
+//   A' [row tile][k-step 0..2KS)[lane][8 halves]   hi segments (k-steps 0..KS) then lo segments; 1 KiB per (tile, k-step)
+//   B' [frame tile][k-step 0..2KS)[lane][8 halves]
+// A workgroup (8 waves, 2 per SIMD) owns 512 frames and one eighth of the rows.  Each wave keeps the fragments of its
+// 64 frames in registers for the whole kernel (B stationary: 2 tiles x 2KS x 4 VGPRs) and streams row tiles from LDS,
+// where the workgroup double-buffers chunks of NT row tiles with LDS-DMA.  The eighth of the rows a workgroup works on
+// is blockIdx.x % 8, i.e. its XCD under round-robin placement, so each XCD's L2 holds "its" 1/8 of A' (1.25 MB at
+// 2000 x 16 x 39) and every chunk after the first comes from L2.  Gaussians are the MFMA rows, frames the columns:
+// a lane's 16 accumulators are the components of whole states for one frame, the mixture log-sum-exp is in-lane.
+#include <cmath>
+
+#include "srx_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int NW16 = 8;          // waves per workgroup
+static constexpr int FT_PER_WAVE = 2;   // 32-frame tiles a wave keeps in registers
+static constexpr int FRAMES_PER_WG = NW16 * FT_PER_WAVE * 32;
+static constexpr int NT16 = 6;          // row tiles per LDS chunk
+static constexpr int NSLICE = 8;        // row slices = XCDs
+static constexpr float kLn2f = 0.69314718055994530942f;
+static constexpr float kPadConst = -30000.0f;  // constant of a padded component: 2^-30000 = 0, representable in f16
+static constexpr float kF16Max = 60000.0f;
+static constexpr float kFrameLimit = 250.0f;   // |x'/s| beyond this is re-evaluated exactly (250^2 < 65504)
+
+static int padded_components16(int M) {
+    int mp = 1;
+    while (mp < M) mp <<= 1;
+    return mp;
+}
+
+// ------------------------------------------------------------------------------------------
+// model side
+// ------------------------------------------------------------------------------------------
+// colstats[0][d] = centre c_d, [1][d] = s_d, [2][d] = 1/s_d.  One block per dimension.
+__global__ __launch_bounds__(256) void k_colstats16(const double *__restrict__ mean, const double *__restrict__ var, int n, int D,
+                                                    float *__restrict__ cs) {
+    const int d = blockIdx.x;
+    __shared__ double red[4];
+    __shared__ float cshared;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double v = mean[(size_t)i * D + d];
+        if (v == v && fabs(v) < 1e300) acc += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) cshared = (float)((red[0] + red[1] + red[2] + red[3]) / n);
+    __syncthreads();
+    const double c = (double)cshared;
+    double mx = 0.0, vx = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double m = mean[(size_t)i * D + d], v = var[(size_t)i * D + d];
+        if (m == m && fabs(m) < 1e300) mx = fmax(mx, fabs(m - c));
+        if (v == v && v > 0 && v < 1e300) vx = fmax(vx, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmax(mx, __shfl_down(mx, o, 64));
+        vx = fmax(vx, __shfl_down(vx, o, 64));
+    }
+    __syncthreads();
+    __shared__ double red2[4];
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = mx;
+        red2[threadIdx.x >> 6] = vx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        vx = fmax(fmax(red2[0], red2[1]), fmax(red2[2], red2[3]));
+        double span = mx + 8.0 * sqrt(vx);
+        int e = 0;
+        if (span > 0 && span < 1e300) e = (int)ceil(log2(span / 8.0));
+        e = e < -40 ? -40 : (e > 40 ? 40 : e);
+        cs[d] = cshared;
+        cs[D + d] = (float)ldexp(1.0, e);
+        cs[2 * D + d] = (float)ldexp(1.0, -e);
+    }
+}
+
+// Coefficient k (0 .. 16*KS) of Gaussian (g, c):  k = 2d -> quadratic, 2d+1 -> linear, 2D -> constant, else 0.
+__device__ __forceinline__ float coef16(const double *__restrict__ mean, const double *__restrict__ var, const float *__restrict__ logwt,
+                                        const float *__restrict__ cs, int G, int M, int D, int Muse, int g, int c, int k, double scale) {
+    if (g >= G || c >= Muse) return k == 2 * D ? kPadConst : 0.0f;
+    const size_t o = (size_t)g * M + c;
+    if (k < 2 * D) {
+        const int d = k >> 1;
+        const double iv = 1.0 / var[o * D + d];
+        const double s = (double)cs[D + d];
+        return (k & 1) ? (float)(scale * iv * (mean[o * D + d] - (double)cs[d]) * s) : (float)(scale * -0.5 * iv * s * s);
+    }
+    if (k == 2 * D) {
+        const double l2pi = (double)(float)-0.4515827052894549;  // (float)log(M_2_PI), src/gmm.cpp:43
+        double acc = 0.0;
+        for (int d = 0; d < D; d++) {
+            const double mu = mean[o * D + d] - (double)cs[d];
+            const double s2 = var[o * D + d];
+            acc += l2pi + log(s2) + mu * mu / s2;
+        }
+        return (float)(scale * ((double)logwt[o] - 0.5 * acc));
+    }
+    return 0.0f;
+}
+
+// One thread per (row tile, k-step, lane): 8 halves.  Row i of a tile <-> (lane half hr = (i>>2)&1, accumulator register
+// r = (i&3) + 4*(i>>3)); register r of half hr is component r % MP of tile-local state hr*(16/MP) + r/MP.
+__global__ __launch_bounds__(256) void k_pack16(const double *__restrict__ mean, const double *__restrict__ var,
+                                                const float *__restrict__ logwt, const float *__restrict__ cs, int G, int M, int D,
+                                                int KS, int MP, int Muse, int ntiles_alloc, f16x8 *__restrict__ packed,
+                                                int *__restrict__ flag) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)ntiles_alloc * 2 * KS * 64) return;
+    const int lane = (int)(idx & 63);
+    const int s = (int)((idx >> 6) % (2 * KS));
+    const int tile = (int)((idx >> 6) / (2 * KS));
+    const int i = lane & 31, hh = lane >> 5;
+    const int hr = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
+    const int st = hr * (16 / MP) + r / MP, c = r % MP;
+    const int g = tile * (32 / MP) + st;
+    const double scale = MP > 1 ? 1.4426950408889634 : 1.0;
+    const bool lo = s >= KS;
+    const int k0 = (lo ? s - KS : s) * 16 + hh * 8;
+    f16x8 out;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float v = coef16(mean, var, logwt, cs, G, M, D, Muse, g, c, k0 + e, scale);
+        if (fabsf(v) > kF16Max && v == v) bad = true;   // NaN parameters pass through as NaN, like the f32 path
+        const _Float16 hi = (_Float16)v;
+        out[e] = lo ? (_Float16)(v - (float)hi) : hi;
+    }
+    packed[idx] = out;
+    if (bad) atomicOr(flag, 1);
+}
+
+static int ensure_packed16(srx_ctx *ctx, srx_model *m, int mix_mode, int KS) {
+    const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
+    const int MP = padded_components16(Muse);
+    if (m->packed16_version == m->version && m->packed16_mode == mix_mode && m->packed16) return SRX_OK;
+    const int spt = 32 / MP;
+    const int ntiles = (m->G + spt - 1) / spt;
+    const int tps = (ntiles + NSLICE - 1) / NSLICE;
+    const int ntiles_alloc = tps * NSLICE + NT16;  // whole slices, plus one chunk the last DMA may run into
+    const size_t bytes = (size_t)ntiles_alloc * 2 * KS * 1024;
+    if (bytes > m->packed16_bytes) {
+        (void)hipFree(m->packed16);
+        m->packed16 = nullptr;
+        m->packed16_bytes = 0;
+        SRX_HIP(ctx, hipMalloc(&m->packed16, bytes));
+        m->packed16_bytes = bytes;
+    }
+    if (!m->colstats) SRX_HIP(ctx, hipMalloc((void **)&m->colstats, 3 * (size_t)m->D * sizeof(float)));
+    if (!m->flag16) SRX_HIP(ctx, hipMalloc((void **)&m->flag16, sizeof(int)));
+    SRX_HIP(ctx, hipMemsetAsync(m->flag16, 0, sizeof(int), ctx->stream));
+    {
+        SrxProf prof_(ctx, "k_colstats16");
+        hipLaunchKernelGGL(k_colstats16, dim3(m->D), dim3(256), 0, ctx->stream, m->mean, m->var, m->G * m->M, m->D, m->colstats);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    const int64_t n = (int64_t)ntiles_alloc * 2 * KS * 64;
+    {
+        SrxProf prof_(ctx, "k_pack16");
+        hipLaunchKernelGGL(k_pack16, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, m->mean, m->var, m->logwt, m->colstats,
+                           m->G, m->M, m->D, KS, MP, Muse, ntiles_alloc, (f16x8 *)m->packed16, m->flag16);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    // the model changed: one 4-byte read-back decides whether its coefficients fit f16
+    int flag = 0;
+    SRX_HIP(ctx, hipMemcpyAsync(&flag, m->flag16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->f16_ok = flag == 0;
+    m->packed16_version = m->version;
+    m->packed16_mode = mix_mode;
+    return SRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// frame side: B' fragments + per-frame "re-evaluate" flags
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep16(const float *__restrict__ feats, int ld, int64_t T, int64_t nft, int D, int KS,
+                                                const float *__restrict__ cs, f16x8 *__restrict__ Bp, unsigned char *__restrict__ fflag) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nft * 2 * KS * 64) return;
+    const int lane = (int)(idx & 63);
+    const int s = (int)((idx >> 6) % (2 * KS));
+    const int64_t ft = (idx >> 6) / (2 * KS);
+    const int j = lane & 31, hh = lane >> 5;
+    const int64_t t = ft * 32 + j;
+    const bool lo = s >= KS;
+    const int k0 = (lo ? s - KS : s) * 16 + hh * 8;
+    f16x8 out;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const int k = k0 + e;  // even: (quadratic, linear) pair of dimension k/2, or (1, 0) at k = 2D
+        float q = 0.0f, l = 0.0f;
+        if (t < T) {
+            if (k < 2 * D) {
+                const int d = k >> 1;
+                l = (feats[t * ld + d] - cs[d]) * cs[2 * D + d];
+                if (!(fabsf(l) <= kFrameLimit)) {  // also catches NaN
+                    bad = true;
+                    l = 0.0f;
+                }
+                q = l * l;
+            } else if (k == 2 * D) {
+                q = 1.0f;
+            }
+        }
+        const _Float16 qh = (_Float16)q, lh = (_Float16)l;
+        out[e] = lo ? (_Float16)(q - (float)qh) : qh;
+        out[e + 1] = lo ? (_Float16)(l - (float)lh) : lh;
+    }
+    Bp[idx] = out;
+    if (bad && !lo) fflag[t] = 1;
+}
+
+// Frames flagged by k_prep16: the whole row of scores, exact evaluation (same code as SRX_SCORE_EXACT).
+__global__ __launch_bounds__(256) void k_gmm_fixup16(const unsigned char *__restrict__ fflag, const float *__restrict__ feats, int ld,
+                                                     int64_t T, int G, int M, int D, const double *__restrict__ mean,
+                                                     const double *__restrict__ var, const float *__restrict__ logwt, int mode,
+                                                     float *__restrict__ out, int64_t st_t, int64_t st_g) {
+    // one wave per 64 frames; a flagged frame is then evaluated by the whole wave, lanes over states
+    const int lane = threadIdx.x & 63;
+    const int64_t t0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+    if (t0 >= T) return;
+    const int64_t tl = t0 + lane;
+    const unsigned long long mask = __ballot(tl < T && fflag[tl] != 0);
+    if (mask == 0) return;
+    for (int b = 0; b < 64; b++) {
+        if (!((mask >> b) & 1ull)) continue;
+        const int64_t t = t0 + b;
+        const float *fv = feats + t * ld;
+        for (int g = lane; g < G; g += 64) {
+            float r;
+            if (mode == SRX_MIX_COMPONENT0) {
+                const size_t o = (size_t)g * M;
+                r = srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D);
+            } else {
+                double s = 0.0;
+                for (int m = 0; m < M; m++) {
+                    const size_t o = (size_t)g * M + m;
+                    s += exp((double)srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D));
+                }
+                r = (float)log(s);
+            }
+            out[t * st_t + (int64_t)g * st_g] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the contraction
+// ------------------------------------------------------------------------------------------
+template <int MP, int KS>
+__global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restrict__ Bp, int64_t T, const f16x8 *__restrict__ Ap,
+                                                          int ntiles, int tps, int G, float *__restrict__ out, int64_t st_t,
+                                                          int64_t st_g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    constexpr int KS2 = 2 * KS;
+    constexpr int TILE_BYTES = KS2 * 1024;
+    constexpr int CHUNK_BYTES = NT16 * TILE_BYTES;
+    constexpr int NPIECE = NT16 * KS2;           // 1 KiB DMA pieces per chunk
+    constexpr int NST = 16 / MP;                 // states per lane half per row tile
+    constexpr int SPT = 32 / MP;                 // states per row tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int slice = blockIdx.x % NSLICE;
+    const int64_t fb = blockIdx.x / NSLICE;
+    const int tile_lo = slice * tps;
+    const int tile_hi = tile_lo + tps < ntiles ? tile_lo + tps : ntiles;
+    if (tile_lo >= tile_hi) return;
+    const int nchunks = (tile_hi - tile_lo + NT16 - 1) / NT16;
+
+    auto dma = [&](int chunk, int buf) {
+        // NPIECE contiguous KiB of A' -> LDS buffer `buf`; piece p is issued by wave p % NW16
+        const char *g = reinterpret_cast<const char *>(Ap) + ((size_t)(tile_lo + chunk * NT16)) * TILE_BYTES + lane * 16;
+        unsigned char *dst = lds16 + buf * CHUNK_BYTES;
+        for (int p = w; p < NPIECE; p += NW16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (size_t)p * 1024),
+                                             (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, 0, 0);
+    };
+    dma(0, 0);
+
+    // this wave's frames: fragments stay in registers for the whole kernel
+    const int64_t ft0 = (fb * NW16 + w) * FT_PER_WAVE;
+    f16x8 Bf[FT_PER_WAVE][KS2];
+#pragma unroll
+    for (int f = 0; f < FT_PER_WAVE; f++)
+#pragma unroll
+        for (int s = 0; s < KS2; s++) Bf[f][s] = Bp[((ft0 + f) * KS2 + s) * 64 + lane];
+
+    for (int c = 0; c < nchunks; c++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c have landed (and its stores drained)
+        __syncthreads();                                  // ... everybody's; and everybody is done with the other buffer
+        if (c + 1 < nchunks) dma(c + 1, (c + 1) & 1);
+        const unsigned char *cb = lds16 + (c & 1) * CHUNK_BYTES + lane * 16;
+        const int nt = (tile_hi - tile_lo - c * NT16) < NT16 ? (tile_hi - tile_lo - c * NT16) : NT16;
+        for (int tt = 0; tt < nt; tt++) {
+            const unsigned char *tb = cb + tt * TILE_BYTES;
+            f16x8 Af[KS2];
+#pragma unroll
+            for (int s = 0; s < KS2; s++) Af[s] = *reinterpret_cast<const f16x8 *>(tb + s * 1024);
+            f32x16 acc[FT_PER_WAVE];
+            const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // small terms first: a_lo b_hi, a_hi b_lo, then a_hi b_hi
+#pragma unroll
+            for (int f = 0; f < FT_PER_WAVE; f++) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[KS], Bf[f][0], z, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < KS; s++)
+#pragma unroll
+                for (int f = 0; f < FT_PER_WAVE; f++)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[KS + s], Bf[f][s], acc[f], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int f = 0; f < FT_PER_WAVE; f++)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s], Bf[f][KS + s], acc[f], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+#pragma unroll
+                for (int f = 0; f < FT_PER_WAVE; f++)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s], Bf[f][s], acc[f], 0, 0, 0);
+
+            // ---- epilogue: per-state log-sum-exp over the lane's registers, store ----
+            const int tile = tile_lo + c * NT16 + tt;
+            const int gbase = tile * SPT + h * NST;
+#pragma unroll
+            for (int f = 0; f < FT_PER_WAVE; f++) {
+                const int64_t fr = (ft0 + f) * 32 + j;
+                float *orow = out + fr * st_t;
+#pragma unroll
+                for (int st = 0; st < NST; st++) {
+                    float v;
+                    if (MP == 1) {
+                        v = acc[f][st];
+                    } else {
+                        float mx = acc[f][st * MP];
+#pragma unroll
+                        for (int q = 1; q < MP; q++) mx = fmaxf(mx, acc[f][st * MP + q]);
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < MP; q++) sum += __builtin_amdgcn_exp2f(acc[f][st * MP + q] - mx);
+                        v = (mx + __builtin_amdgcn_logf(sum)) * kLn2f;
+                    }
+                    const int g = gbase + st;
+                    if (fr < T && g < G) orow[(int64_t)g * st_g] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MP, int KS>
+static int launch_f16(srx_ctx *ctx, srx_model *m, const f16x8 *Bp, int64_t T, int64_t nfb, float *out, int64_t st_t, int64_t st_g) {
+    const size_t lds_bytes = (size_t)2 * NT16 * 2 * KS * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_f16<MP, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int spt = 32 / MP;
+    const int ntiles = (m->G + spt - 1) / spt;
+    const int tps = (ntiles + NSLICE - 1) / NSLICE;
+    SRX_REQUIRE(ctx, nfb * NSLICE < (1ll << 31), "srx_gmm_score: too many frames for one launch");
+    {
+        SrxProf prof_(ctx, "k_gmm_f16");
+        hipLaunchKernelGGL((k_gmm_f16<MP, KS>), dim3((unsigned)(nfb * NSLICE)), dim3(64 * NW16), lds_bytes, ctx->stream, Bp, T,
+                           (const f16x8 *)m->packed16, ntiles, tps, m->G, out, st_t, st_g);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+template <int KS>
+static int dispatch_mp16(srx_ctx *ctx, srx_model *m, int MP, const f16x8 *Bp, int64_t T, int64_t nfb, float *out, int64_t st_t,
+                         int64_t st_g) {
+    switch (MP) {
+        case 1: return launch_f16<1, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
+        case 2: return launch_f16<2, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
+        case 4: return launch_f16<4, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
+        case 8: return launch_f16<8, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
+        case 16: return launch_f16<16, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
+    }
+    return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "srx_gmm_score: unsupported component count");
+}
+
+int srx_gmm_score_mfma(srx_ctx *ctx, srx_model *m, int mix_mode, const float *feats, int ld, int64_t T, float *out, int64_t st_t,
+                       int64_t st_g);
+
+// Called by srx_gmm_score_dev (srx_gmm.hip) after argument validation.
+int srx_gmm_score_f16x3(srx_ctx *ctx, srx_model *m, int mix_mode, const float *feats, int ld, int64_t T, float *out, int64_t st_t,
+                        int64_t st_g) {
+    const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
+    if (2 * m->D + 1 > 80 || Muse > 16)  // K beyond five k-steps / more components than a lane's accumulators
+        return srx_gmm_score_mfma(ctx, m, mix_mode, feats, ld, T, out, st_t, st_g);
+    const int KS = 2 * m->D + 1 <= 32 ? 2 : 5;
+    int rc = ensure_packed16(ctx, m, mix_mode, KS);
+    if (rc != SRX_OK) return rc;
+    if (!m->f16_ok) return srx_gmm_score_mfma(ctx, m, mix_mode, feats, ld, T, out, st_t, st_g);
+    const int MP = padded_components16(Muse);
+    const int64_t nfb = (T + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+    const int64_t nft = nfb * NW16 * FT_PER_WAVE;
+    const size_t b_bytes = (size_t)nft * 2 * KS * 1024;
+    void *ws = nullptr;
+    rc = srx_workspace(ctx, 0, b_bytes + (size_t)T + 256, &ws);
+    if (rc != SRX_OK) return rc;
+    f16x8 *Bp = reinterpret_cast<f16x8 *>(ws);
+    unsigned char *fflag = reinterpret_cast<unsigned char *>(ws) + b_bytes;
+    SRX_HIP(ctx, hipMemsetAsync(fflag, 0, (size_t)T, ctx->stream));
+    const int64_t n = nft * 2 * KS * 64;
+    SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_gmm_score: too many frames");
+    {
+        SrxProf prof_(ctx, "k_prep16");
+        hipLaunchKernelGGL(k_prep16, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats, ld, T, nft, m->D, KS, m->colstats,
+                           Bp, fflag);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    rc = KS == 2 ? dispatch_mp16<2>(ctx, m, MP, Bp, T, nfb, out, st_t, st_g) : dispatch_mp16<5>(ctx, m, MP, Bp, T, nfb, out, st_t, st_g);
+    if (rc != SRX_OK) return rc;
+    {
+        SrxProf prof_(ctx, "k_gmm_fixup16");
+        hipLaunchKernelGGL(k_gmm_fixup16, dim3((unsigned)ceil_div64(T, 256)), dim3(256), 0, ctx->stream, fflag, feats, ld, T, m->G, m->M,
+                           m->D, m->mean, m->var, m->logwt, mix_mode, out, st_t, st_g);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}

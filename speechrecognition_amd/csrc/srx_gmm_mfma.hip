@@ -107,7 +107,7 @@ static int ensure_packed(srx_ctx *ctx, srx_model *m, int mix_mode, int KSP) {
     const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
     const int MP = padded_components(Muse);
     if (MP > 16) return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "MFMA scoring supports at most 16 mixture components (got %d)", Muse);
-    if (!m->dirty && m->packed_mode == mix_mode && m->packed) return SRX_OK;
+    if (m->packed_version == m->version && m->packed_mode == mix_mode && m->packed) return SRX_OK;
     const int spt = 32 / MP;  // states per row tile
     int ntiles = (m->G + spt - 1) / spt;
     ntiles = (ntiles + 3) / 4 * 4;  // whole groups of 4 tiles so any RT divides
@@ -131,7 +131,7 @@ static int ensure_packed(srx_ctx *ctx, srx_model *m, int mix_mode, int KSP) {
                            m->G, m->M, m->D, KSP, MP, Muse, ntiles, m->packed);
     }
     SRX_LAUNCH_CHECK(ctx);
-    m->dirty = false;
+    m->packed_version = m->version;
     m->packed_mode = mix_mode;
     return SRX_OK;
 }

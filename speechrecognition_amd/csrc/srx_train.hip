@@ -14,21 +14,6 @@
 
 #include "srx_common.h"
 
-__device__ __forceinline__ float logprob_exact(const float *__restrict__ fv, const double *__restrict__ mean,
-                                               const double *__restrict__ var, float logwt, int D) {
-    // gaussian::operator()  src/gmm.cpp:41-49
-    float res = 0.0f;
-    const float l2pi = (float)-0.4515827052894549;
-    for (int i = 0; i < D; i++) {
-        float t = (float)((double)fv[i] - mean[i]);
-        float tt = t * t;
-        double term = ((double)l2pi + log(var[i])) + (double)tt / var[i];
-        res = (float)((double)res + term);
-    }
-    float h = -0.5f * res;
-    return h + logwt;
-}
-
 __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
     // total order trick: non-negative floats order like ints, negative floats reversed like uints
     if (v >= 0.0f)
@@ -66,7 +51,7 @@ __global__ __launch_bounds__(256) void k_em_logp(const float *__restrict__ feats
     const int g = gid[t];
     if (g < 0) { logp[idx] = 0.0f; return; }
     const size_t o = (size_t)g * M + m;
-    const float lp = logprob_exact(feats + t * ld, mean + o * D, var + o * D, logwt[o], D);
+    const float lp = srx_logprob_exact(feats + t * ld, mean + o * D, var + o * D, logwt[o], D);
     logp[idx] = lp;
     if (lp == lp) atomic_max_float(&shift[o], lp);
 }
@@ -293,7 +278,7 @@ extern "C" int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1
                            B->mean, B->var, B->weight, B->logwt);
     }
     SRX_LAUNCH_CHECK(ctx);
-    B->dirty = true;
+    B->version++;
     return SRX_OK;
 }
 
@@ -318,6 +303,6 @@ extern "C" int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const
                            stats2_dev, A->mean, A->var, A->weight, B->mean, B->var, B->weight, B->logwt, blend_keep);
     }
     SRX_LAUNCH_CHECK(ctx);
-    B->dirty = true;
+    B->version++;
     return SRX_OK;
 }

@@ -1,0 +1,177 @@
+"""Parity of the split-f16 MFMA scoring path (SRX_SCORE_MFMA_F16X3, srx_gmm_f16.hip) against the oracle.
+
+Same bar as the f32-input path (north_star: log-likelihoods within 1e-4 relative):
+|a-b| <= 1e-4 * max(|a|, |b|, 1).  Three f16 products per term keep ~22 significant bits; the cases below include
+what f16 cannot represent (tiny variances -> routed to the f32-input kernel; frames far outside the model or NaN ->
+re-evaluated exactly by k_gmm_fixup16)."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP, host, synth
+from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3 as F16
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=1e-4):
+    return np.abs(a - b) <= tol * np.maximum(np.maximum(np.abs(a), np.abs(b)), 1.0)
+
+
+def _feats(T, ld, seed, scale=1.3, offset=0.0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((T, ld)) * scale + offset).astype(np.float32)
+
+
+def test_reference_native_shape_D13_M1_G40(ctx, oracle):
+    G, M, D = 40, 1, 13
+    mean, var, w = synth.random_model(G, M, D, 1)
+    w[:] = 1.0
+    feats = _feats(777, 39, 2)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    ref = oracle.gmm_score(feats, mean, var, oracle.set_wt(w), D, 0)
+    got = model.score(feats, SRX_MIX_COMPONENT0, F16)
+    assert _close(got, ref).all(), np.abs(got - ref).max()
+    assert _close(got, ref, 2e-5).all()        # measured margin: the split keeps ~22 bits
+    model.close()
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize("D", [39, 20, 13])
+def test_mixtures_logsumexp_and_component0(ctx, oracle, M, D):
+    G = 70
+    mean, var, w = synth.random_model(G, M, D, 10 + M + D)
+    feats = _feats(300, 39, 3)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    lw = oracle.set_wt(w)
+    for mode in (SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP):
+        ref = oracle.gmm_score(feats, mean, var, lw, D, mode)
+        got = model.score(feats, mode, F16)
+        assert _close(got, ref).all(), (mode, np.abs(got - ref).max())
+    model.close()
+
+
+def test_bench_shape_slice_G2000_M16_D39(ctx, oracle):
+    """The benchmark's model (all 8 row slices, several LDS chunks per slice) on a few hundred frames."""
+    G, M, D, T = 2000, 16, 39, 600
+    mean, var, w = synth.random_model(G, M, D, 777)
+    feats = _feats(T, 39, 5)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    got = model.score(feats, SRX_MIX_LOGSUMEXP, F16)
+    cols = np.r_[0:40, 990:1030, 1960:2000]
+    sub = np.ascontiguousarray
+    ref = oracle.gmm_score(feats, sub(mean[cols]), sub(var[cols]), oracle.set_wt(sub(w[cols])), D, 1)
+    assert _close(got[:, cols], ref).all(), np.abs(got[:, cols] - ref).max()
+    # every column agrees with the f32-input MFMA path
+    f32 = model.score(feats, SRX_MIX_LOGSUMEXP, 0)
+    assert _close(got, f32).all()
+    model.close()
+
+
+def test_offset_features_and_tiny_variance_falls_back(ctx, oracle):
+    """Common offset 50 (raw cepstra are not centred); a variance of 1e-4 next to variances of ~1 gives a coefficient
+    beyond the f16 range: the model is routed to the f32-input kernel and the stress rows still hold the bar."""
+    G, M, D = 33, 1, 13
+    rng = np.random.default_rng(4)
+    mean = rng.standard_normal((G, M, D)) + 50.0
+    var = rng.uniform(0.5, 1.5, (G, M, D))
+    w = np.ones((G, M), np.float32)
+    feats = _feats(200, 39, 5, 1.0, 50.0)
+    feats[0, :13] = mean[1, 0] + 30.0
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    ref = oracle.gmm_score(feats, mean, var, np.zeros_like(w), D, 0)
+    got = model.score(feats, SRX_MIX_COMPONENT0, F16)
+    assert _close(got, ref).all(), np.abs(got - ref).max()
+    # the f32 path's own stress row (tests/test_gpu_gmm.py): variance 1e-4, frame 0.003 off the mean -- still inside f16
+    var[0] = 1e-4
+    feats[1, :13] = mean[0, 0] + 0.003
+    model.set(mean, var, w)
+    ref = oracle.gmm_score(feats, mean, var, np.zeros_like(w), D, 0)
+    got = model.score(feats, SRX_MIX_COMPONENT0, F16)
+    assert _close(got, ref).all(), np.abs(got - ref).max()
+    # variance 1e-6: -s^2/(2 var) is beyond the f16 range -> the call is served by the f32-input kernel, bit for bit
+    var[0] = 1e-6
+    model.set(mean, var, w)
+    got = model.score(feats, SRX_MIX_COMPONENT0, F16)
+    f32 = model.score(feats, SRX_MIX_COMPONENT0, 0)
+    assert got.tobytes() == f32.tobytes()
+    ref = oracle.gmm_score(feats, mean, var, np.zeros_like(w), D, 0)
+    assert _close(got[:, 1:], ref[:, 1:]).all()
+    model.close()
+
+
+def test_outlier_and_nan_frames_are_reevaluated_exactly(ctx, oracle):
+    G, M, D, T = 21, 4, 39, 500
+    mean, var, w = synth.random_model(G, M, D, 31)
+    feats = _feats(T, 39, 6)
+    feats[7, 3] = 4.0e4            # far outside the model: (x'/s)^2 overflows f16
+    feats[300, :] = -9.0e3
+    feats[499, 38] = np.nan
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    lw = oracle.set_wt(w)
+    for mode in (SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP):
+        ref = oracle.gmm_score(feats, mean, var, lw, D, mode)
+        got = model.score(feats, mode, F16)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) or mode == SRX_MIX_LOGSUMEXP
+        assert _close(got[fin], ref[fin]).all(), (mode, np.abs(got[fin] - ref[fin]).max())
+        assert np.isnan(got[499]).all() or mode == SRX_MIX_LOGSUMEXP
+        # component-0 scores of the outlier rows are finite and huge: they must match, not saturate
+        if mode == SRX_MIX_COMPONENT0:
+            assert np.isfinite(ref[7]).all() and np.abs(ref[7]).min() > 1e6
+    model.close()
+
+
+def test_nan_model_rows_stay_nan(ctx, oracle):
+    """Tied states never visited in an EM iteration have NaN parameters (reference behaviour): their scores are NaN,
+    everything else is unaffected."""
+    G, M, D = 12, 2, 13
+    mean, var, w = synth.random_model(G, M, D, 8)
+    mean[5] = np.nan
+    var[5] = np.nan
+    feats = _feats(130, 39, 9)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    got = model.score(feats, SRX_MIX_LOGSUMEXP, F16)
+    ref = oracle.gmm_score(feats, mean, var, oracle.set_wt(w), D, 1)
+    assert np.isnan(got[:, 5]).all() and np.isnan(ref[:, 5]).all()
+    keep = np.arange(G) != 5
+    assert _close(got[:, keep], ref[:, keep]).all()
+    model.close()
+
+
+def test_ragged_T_ld_and_state_major(ctx, oracle):
+    G, M, D = 5, 2, 7
+    mean, var, w = synth.random_model(G, M, D, 6)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    for T in (1, 31, 32, 33, 511, 512, 513, 1500):
+        feats = _feats(T, 9, T)
+        ref = oracle.gmm_score(feats, mean, var, oracle.set_wt(w), D, 1)
+        got = model.score(feats, SRX_MIX_LOGSUMEXP, F16)
+        assert _close(got, ref).all(), T
+        out_d = ctx.zeros((G, T), np.float32)
+        model.score_dev(ctx.array(feats), 9, T, out_d, 1, T, SRX_MIX_LOGSUMEXP, F16)
+        ctx.sync()
+        assert _close(out_d.get().T, ref).all(), T
+    assert model.score(np.zeros((0, 9), np.float32), SRX_MIX_LOGSUMEXP, F16).shape == (0, G)
+    model.close()
+
+
+def test_model_update_is_picked_up(ctx, oracle):
+    G, M, D = 9, 4, 39
+    mean, var, w = synth.random_model(G, M, D, 2)
+    feats = _feats(100, 39, 1)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    a = model.score(feats, SRX_MIX_LOGSUMEXP, F16)
+    mean2 = mean + 0.5
+    model.set(mean2, var, w)
+    b = model.score(feats, SRX_MIX_LOGSUMEXP, F16)
+    ref = oracle.gmm_score(feats, mean2, var, oracle.set_wt(w), D, 1)
+    assert _close(b, ref).all() and not _close(a, ref).all()
+    model.close()
