@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 
 WL, HOP, NCEPS, NFILT, FEND, SPS = 400, 160, 13, 48, 7200.0, 16000
 G, M, D = 2000, 16, 39
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: f32-input MFMA (= vector rate)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense BF16/F16 MFMA, ~2.5 PFLOP/s
 PEAK_HBM_GBS = 8000.0
 
 
@@ -121,6 +122,8 @@ def main():
     ap.add_argument("--utts", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--frame-major", action="store_true", help="emission matrix as [T][G] instead of [G][T]")
+    ap.add_argument("--score-path", choices=["f16x3", "f32"], default="f16x3",
+                    help="GMM scoring kernel: split-f16 MFMA (default) or f32-input MFMA")
     args = ap.parse_args()
 
     import torch
@@ -138,6 +141,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from speechrecognition_amd import SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA, host, synth
+    from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3
+    score_path = SRX_SCORE_MFMA_F16X3 if args.score_path == "f16x3" else SRX_SCORE_MFMA
+    gmm_kernel, gmm_prep = ("k_gmm_f16", "k_prep16") if args.score_path == "f16x3" else ("k_gmm_mfma", "k_gmm_prep")
     stream = torch.cuda.Stream()   # a real (non-null) stream: libsrx launches on it and the events below time it
     torch.cuda.set_stream(stream)
     ctx = host.Context(local, stream.cuda_stream)
@@ -175,7 +181,7 @@ def main():
         if timed: e[1].record(stream)
         host.read_features_dev(ctx, 2, NCEPS, ceps_d, hb.frame_off_d, n_utt, T, feats_d)
         if timed: e[2].record(stream)
-        model.score_dev(feats_d, 3 * NCEPS, T, emis_d, ST_T, ST_G, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA)
+        model.score_dev(feats_d, 3 * NCEPS, T, emis_d, ST_T, ST_G, SRX_MIX_LOGSUMEXP, score_path)
         if timed: e[3].record(stream)
         hb.viterbi(emis_d, ST_T, ST_G, 1e10, path_d, final_d, status_d)
         if timed: e[4].record(stream)
@@ -199,7 +205,7 @@ def main():
             stage_ms[name] += e[k].elapsed_time(e[k + 1]) / args.steps
 
     kernel_ms = {}
-    for k in ("k_sumsq_scale", "k_mfcc_tile", "k_features", "k_gmm_prep", "k_gmm_mfma", "k_viterbi"):
+    for k in ("k_sumsq_scale", "k_mfcc_tile", "k_features", gmm_prep, gmm_kernel, "k_viterbi"):
         ms, n = ctx.profile_query(k)
         assert n == args.steps, (k, n)
         kernel_ms[k] = ms / n
@@ -220,7 +226,9 @@ def main():
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
         flop_per_frame = 2.0 * (2 * D + 1) * G * M          # GMM scoring, all states
-        gmm_tflops = flop_per_frame * T / (kernel_ms["k_gmm_mfma"] * 1e-3) / 1e12
+        gmm_tflops = flop_per_frame * T / (kernel_ms[gmm_kernel] * 1e-3) / 1e12
+        f16 = args.score_path == "f16x3"
+        gmm_peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
         mfcc_bytes = (HOP * 4 + NCEPS * 4) * T               # 692 B/frame
         mfcc_ms, vit_ms = kernel_ms["k_mfcc_tile"], kernel_ms["k_viterbi"]
         vit_S = float(np.mean([len(n) for n in ntrs]))
@@ -229,17 +237,22 @@ def main():
             "metric": "audio frames/sec (node) through MFCC+GMM+Viterbi",
             "value": frames_all * args.steps / dt_max, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16x3 split operands, f32 accumulate" if f16 else "f32", "data": "synthetic",
             "config": {"workload": "configs[1] corpus: 1000 synthetic Voxforge-shaped utterances (2-8 s, 16 kHz) per GPU -> "
                                    "MFCC 25ms/10ms, 48 mel filters, 13 ceps -> smoothing+deltas (39 dims) -> dense GMM "
                                    "scoring 2000 tied states x 16 diag Gaussians x 39 dims (log-sum-exp) -> Viterbi forced "
                                    "alignment of every utterance",
                        "utterances_per_gpu": n_utt, "frames_per_gpu": T, "window": WL, "hop": HOP, "G": G, "M": M, "D": D,
                        "mean_states_per_utt": vit_S, "parallelism": f"utterance-sharded x{world}"},
-            "roofline": {"bound": "mfma", "achieved": gmm_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gmm_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic("k_gmm_mfma", T),
-                         "kernel": "k_gmm_mfma<16,4>", "flop_per_frame": flop_per_frame,
-                         "ms_per_launch": kernel_ms["k_gmm_mfma"]},
+            # achieved = ALGORITHMIC flops (2*(2D+1)*G*M per frame) / kernel time.  The f16x3 kernel executes three
+            # f16 products per algorithmic product, so its ceiling in these units is 1/3 of the f16 MFMA peak;
+            # against the f32-input MFMA peak (the only other way to hold the 1e-4 bar) see "vs_f32_mfma_peak".
+            "roofline": {"bound": "mfma", "achieved": gmm_tflops, "peak": gmm_peak, "unit": "TFLOP/s",
+                         "frac": gmm_tflops / gmm_peak, "traffic": pmc_traffic(gmm_kernel, T),
+                         "kernel": "k_gmm_f16<16,5>" if f16 else "k_gmm_mfma<16,4>", "flop_per_frame": flop_per_frame,
+                         "ms_per_launch": kernel_ms[gmm_kernel], "executed_over_algorithmic_flops": 3 if f16 else 1,
+                         "mfma_executed_frac_of_peak": (3 if f16 else 1) * gmm_tflops / gmm_peak,
+                         "vs_f32_mfma_peak": gmm_tflops / PEAK_F32_MFMA_TFLOPS},
             "stages_ms": stage_ms, "kernels_ms": kernel_ms,
             "stage_rooflines": {
                 "mfcc_hbm": {"kernel": "k_mfcc_tile", "achieved_GBs": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9,

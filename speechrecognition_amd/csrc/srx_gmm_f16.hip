@@ -30,6 +30,7 @@
 #include <cmath>
 
 #include "srx_common.h"
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -161,7 +162,7 @@ static int ensure_packed16(srx_ctx *ctx, srx_model *m, int mix_mode, int KS) {
     if (m->packed16_version == m->version && m->packed16_mode == mix_mode && m->packed16) return SRX_OK;
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;
-    const int tps = (ntiles + NSLICE - 1) / NSLICE;
+    const int tps = (ntiles + NSLICE - 1) / NSLICE + 8;   // slices are rounded up to whole output groups (<= 8 tiles)
     const int ntiles_alloc = tps * NSLICE + NT16;  // whole slices, plus one chunk the last DMA may run into
     const size_t bytes = (size_t)ntiles_alloc * 2 * KS * 1024;
     if (bytes > m->packed16_bytes) {
@@ -274,30 +275,70 @@ __global__ __launch_bounds__(256) void k_gmm_fixup16(const unsigned char *__rest
 // ------------------------------------------------------------------------------------------
 // the contraction
 // ------------------------------------------------------------------------------------------
-template <int MP, int KS>
+// Per-(MP) tiling constants shared by the kernel and its launcher.
+template <int MP>
+struct F16Cfg {
+    static constexpr int NST = 16 / MP;                       // states per lane half per row tile
+    static constexpr int SPT = 32 / MP;                       // states per row tile
+    static constexpr int GT = SPT >= 8 ? 1 : 8 / SPT;         // row tiles per output group (a group = a multiple of 8 states)
+    static constexpr int RG = SPT * GT;                       // states (staging rows) per group
+    static constexpr int NT = MP == 1 ? 4 : 6;                // row tiles per LDS chunk
+    static constexpr int STAGE_FLOATS = FT_PER_WAVE * RG * 32;  // per wave
+};
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), in order
+template <int... Is, class F>
+__device__ __forceinline__ void static_for16(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+__device__ __forceinline__ void wait_vmcnt_at_most(int n) {
+    // s_waitcnt takes an immediate; n is wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+// WIDE: state-major output (stride_t == 1).  The per-state results of a group of row tiles are staged in a wave-private
+// LDS tile [state][32 frames] and leave as global_store_dwordx4 (four consecutive frames per lane, 1 KiB per
+// instruction).  A CU retires roughly one store instruction per ~100 cycles whatever its width: with one dword per
+// lane the 4 GB emission matrix cost as much as all the MFMAs and did not overlap them.
+template <int MP, int KS, bool WIDE>
 __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restrict__ Bp, int64_t T, const f16x8 *__restrict__ Ap,
                                                           int ntiles, int tps, int G, float *__restrict__ out, int64_t st_t,
-                                                          int64_t st_g) {
+                                                          int64_t st_g, float *__restrict__ dump) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    typedef F16Cfg<MP> Cfg;
     constexpr int KS2 = 2 * KS;
+    constexpr int NT = Cfg::NT;
     constexpr int TILE_BYTES = KS2 * 1024;
-    constexpr int CHUNK_BYTES = NT16 * TILE_BYTES;
-    constexpr int NPIECE = NT16 * KS2;           // 1 KiB DMA pieces per chunk
-    constexpr int NST = 16 / MP;                 // states per lane half per row tile
-    constexpr int SPT = 32 / MP;                 // states per row tile
+    constexpr int CHUNK_BYTES = NT * TILE_BYTES;
+    constexpr int NPIECE = NT * KS2;             // 1 KiB DMA pieces per chunk
+    constexpr int NST = Cfg::NST, SPT = Cfg::SPT, GT = Cfg::GT, RG = Cfg::RG;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int slice = blockIdx.x % NSLICE;
     const int64_t fb = blockIdx.x / NSLICE;
     const int tile_lo = slice * tps;
-    const int tile_hi = tile_lo + tps < ntiles ? tile_lo + tps : ntiles;
+    // tps is even: a slice holds whole pairs of row tiles.  A pair may end one tile past ntiles; that tile is padding in
+    // A' (states >= G, never stored).
+    const int tile_hi = tile_lo + tps < ntiles + (ntiles & 1) ? tile_lo + tps : ntiles + (ntiles & 1);
     if (tile_lo >= tile_hi) return;
-    const int nchunks = (tile_hi - tile_lo + NT16 - 1) / NT16;
+    const int nchunks = (tile_hi - tile_lo + NT - 1) / NT;
+    float *stage = reinterpret_cast<float *>(lds16 + 2 * CHUNK_BYTES) + w * Cfg::STAGE_FLOATS;  // [FT][RG][32]
 
-    auto dma = [&](int chunk, int buf) {
+    auto dma = [&](int chunk, int buf) __attribute__((always_inline)) {
         // NPIECE contiguous KiB of A' -> LDS buffer `buf`; piece p is issued by wave p % NW16
-        const char *g = reinterpret_cast<const char *>(Ap) + ((size_t)(tile_lo + chunk * NT16)) * TILE_BYTES + lane * 16;
+        const char *g = reinterpret_cast<const char *>(Ap) + ((size_t)(tile_lo + chunk * NT)) * TILE_BYTES + lane * 16;
         unsigned char *dst = lds16 + buf * CHUNK_BYTES;
         for (int p = w; p < NPIECE; p += NW16)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (size_t)p * 1024),
@@ -312,84 +353,228 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
     for (int f = 0; f < FT_PER_WAVE; f++)
 #pragma unroll
         for (int s = 0; s < KS2; s++) Bf[f][s] = Bp[((ft0 + f) * KS2 + s) * 64 + lane];
+    // wave-uniform: every frame of this wave exists, so a lane's four consecutive frames can leave as one dwordx4
+    const bool full_frames = (ft0 + FT_PER_WAVE) * 32 <= T;
 
-    for (int c = 0; c < nchunks; c++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk c have landed (and its stores drained)
-        __syncthreads();                                  // ... everybody's; and everybody is done with the other buffer
-        if (c + 1 < nchunks) dma(c + 1, (c + 1) & 1);
-        const unsigned char *cb = lds16 + (c & 1) * CHUNK_BYTES + lane * 16;
-        const int nt = (tile_hi - tile_lo - c * NT16) < NT16 ? (tile_hi - tile_lo - c * NT16) : NT16;
-        for (int tt = 0; tt < nt; tt++) {
-            const unsigned char *tb = cb + tt * TILE_BYTES;
-            f16x8 Af[KS2];
+    // Software pipeline: the epilogue of row tile n-1 (VALU: max / exp2 / sum / log per state) is issued between the
+    // MFMAs of row tile n, which write a second set of accumulators.  Per 32x32 tile the matrix core is busy 15 x 32
+    // cycles while the epilogue needs ~320 cycles of vector issue per lane: left as two phases they serialise (the two
+    // waves of a SIMD run in lockstep between workgroup barriers), interleaved they overlap.  The interleave is written
+    // out by hand -- slice i of the epilogue after MFMA i, order pinned with sched_barrier -- because the scheduler
+    // otherwise clusters the MFMAs.
+    constexpr int NMF = 3 * KS * FT_PER_WAVE;          // MFMAs per row tile
+    constexpr int NEL = 16 * FT_PER_WAVE;              // accumulator registers (elements) per row tile
+    constexpr int N1 = NMF >= 12 ? 2 : 1;              // slices for the per-state maxima
+    constexpr int N3 = NMF >= 12 ? 2 : 1;              // slices for log / scale / hand-over
+    constexpr int N2 = NMF - N1 - N3;                  // slices for exp2 + sum
+    // two accumulator sets that swap roles from tile to tile (no register copies): one is written by the MFMAs of the
+    // current tile while the epilogue consumes the other
+    f32x16 accA[FT_PER_WAVE], accB[FT_PER_WAVE];
+    int tile_prev = -1;         // tile whose results await their epilogue (-1: none yet)
+    const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < KS2; s++) Af[s] = *reinterpret_cast<const f16x8 *>(tb + s * 1024);
-            f32x16 acc[FT_PER_WAVE];
-            const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            // small terms first: a_lo b_hi, a_hi b_lo, then a_hi b_hi
-#pragma unroll
-            for (int f = 0; f < FT_PER_WAVE; f++) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[KS], Bf[f][0], z, 0, 0, 0);
-#pragma unroll
-            for (int s = 1; s < KS; s++)
-#pragma unroll
-                for (int f = 0; f < FT_PER_WAVE; f++)
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[KS + s], Bf[f][s], acc[f], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < KS; s++)
-#pragma unroll
-                for (int f = 0; f < FT_PER_WAVE; f++)
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s], Bf[f][KS + s], acc[f], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < KS; s++)
-#pragma unroll
-                for (int f = 0; f < FT_PER_WAVE; f++)
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[s], Bf[f][s], acc[f], 0, 0, 0);
+    for (int f = 0; f < FT_PER_WAVE; f++) accA[f] = accB[f] = z;
+    float mx[FT_PER_WAVE][NST], sum[FT_PER_WAVE][NST];
+    int pend_stores = 0;        // store instructions issued since the last DMA issue (wave-uniform)
 
-            // ---- epilogue: per-state log-sum-exp over the lane's registers, store ----
-            const int tile = tile_lo + c * NT16 + tt;
-            const int gbase = tile * SPT + h * NST;
+    // slice `i` (compile-time after unrolling) of the epilogue of the tile whose accumulators are in accp.
+    // pin(): an empty asm the value passes through.  The arithmetic of a slice is pure, so instruction selection would
+    // otherwise place it wherever it likes (it clustered all 32 v_sub/v_exp between two MFMAs); with its inputs pinned at
+    // the start of the slice and its results at the end, each slice stays between its two MFMAs.
+    auto pin = [](float &x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
+    auto epi_slice = [&](auto ic, const f32x16 (&accp)[FT_PER_WAVE]) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;   // compile-time, so that every range below is a constant
+        if constexpr (i < N1) {
+            if constexpr (MP > 1) {
+                constexpr int f0 = i * FT_PER_WAVE / N1, f1 = (i + 1) * FT_PER_WAVE / N1;
 #pragma unroll
-            for (int f = 0; f < FT_PER_WAVE; f++) {
-                const int64_t fr = (ft0 + f) * 32 + j;
-                float *orow = out + fr * st_t;
+                for (int f = f0; f < f1; f++) {
+#pragma unroll
+                    for (int st = 0; st < NST; st++) {
+                        float m_ = accp[f][st * MP];
+                        pin(m_);
+#pragma unroll
+                        for (int q = 1; q < MP; q++) m_ = fmaxf(m_, accp[f][st * MP + q]);
+                        pin(m_);
+                        mx[f][st] = m_;
+                        sum[f][st] = 0.0f;
+                    }
+                }
+            }
+        } else if constexpr (i < N1 + N2) {
+            if constexpr (MP > 1) {
+                constexpr int e0 = (i - N1) * NEL / N2, e1 = (i - N1 + 1) * NEL / N2;
+#pragma unroll
+                for (int e = e0; e < e1; e++) {
+                    const int f = e / 16, r = e % 16;
+                    float a_ = accp[f][r];
+                    pin(a_);
+                    float s_ = sum[f][r / MP] + __builtin_amdgcn_exp2f(a_ - mx[f][r / MP]);
+                    pin(s_);
+                    sum[f][r / MP] = s_;
+                }
+            }
+        } else {
+            constexpr int k = i - N1 - N2;
+            constexpr int f0 = k * FT_PER_WAVE / N3, f1 = (k + 1) * FT_PER_WAVE / N3;
+            const int tl = tile_prev < 0 ? 0 : tile_prev - tile_lo;   // slice-local tile index
+#pragma unroll
+            for (int f = f0; f < f1; f++) {
 #pragma unroll
                 for (int st = 0; st < NST; st++) {
                     float v;
-                    if (MP == 1) {
-                        v = acc[f][st];
+                    if constexpr (MP == 1) {
+                        v = accp[f][st];
                     } else {
-                        float mx = acc[f][st * MP];
-#pragma unroll
-                        for (int q = 1; q < MP; q++) mx = fmaxf(mx, acc[f][st * MP + q]);
-                        float sum = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < MP; q++) sum += __builtin_amdgcn_exp2f(acc[f][st * MP + q] - mx);
-                        v = (mx + __builtin_amdgcn_logf(sum)) * kLn2f;
+                        float s_ = sum[f][st];
+                        pin(s_);
+                        v = (mx[f][st] + __builtin_amdgcn_logf(s_)) * kLn2f;
                     }
-                    const int g = gbase + st;
-                    if (fr < T && g < G) orow[(int64_t)g * st_g] = v;
+                    pin(v);
+                    if (WIDE) {
+                        // staging row = state within the group
+                        stage[(f * RG + (tl % GT) * SPT + h * NST + st) * 32 + j] = v;
+                    } else {
+                        const int64_t fr = (ft0 + f) * 32 + j;
+                        const int g = tile_prev * SPT + h * NST + st;
+                        // branch-free (a conditional store would split the basic block and undo the interleave):
+                        // lanes with nothing to write store to a dump slot
+                        float *dst = (tile_prev >= 0 && fr < T && g < G) ? out + fr * st_t + (int64_t)g * st_g : dump + lane;
+                        *dst = v;
+                    }
                 }
             }
         }
+    };
+
+    // WIDE: write the staged group that ends with slice-local tile `tl_last` (ntl tiles of it are valid)
+    auto flush_group = [&](int tl_last) __attribute__((always_inline)) {
+        const int gfirst = (tile_lo + tl_last / GT * GT) * SPT;      // first state of the group
+        const int nrows = (tl_last % GT + 1) * SPT;                  // staged rows that hold results
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the wave's staging writes have been issued and retired
+#pragma unroll
+        for (int f = 0; f < FT_PER_WAVE; f++)
+#pragma unroll
+            for (int b = 0; b < RG / 8; b++) {
+                const int row = b * 8 + (lane >> 3);
+                const int fq = (lane & 7) * 4;
+                const float4 v = *reinterpret_cast<const float4 *>(stage + (f * RG + row) * 32 + fq);
+                const int g = gfirst + row;
+                const int64_t fr = (ft0 + f) * 32 + fq;
+                float *dst = out + (int64_t)g * st_g + fr;
+                if (row < nrows && g < G) {
+                    if (full_frames) {
+                        *reinterpret_cast<float4 *>(dst) = v;
+                    } else {
+                        if (fr < T) dst[0] = v.x;
+                        if (fr + 1 < T) dst[1] = v.y;
+                        if (fr + 2 < T) dst[2] = v.z;
+                        if (fr + 3 < T) dst[3] = v.w;
+                    }
+                }
+            }
+        pend_stores += FT_PER_WAVE * (RG / 8);
+    };
+
+    for (int c = 0; c < nchunks; c++) {
+        // This wave's DMA pieces of chunk c must have landed.  In flight, oldest first: [pieces of chunk c][the stores
+        // issued since those pieces were issued].  vmcnt retires in order, so waiting until at most that many operations
+        // are outstanding waits for the pieces and leaves the stores in flight.  (Waves that may take the scalar-store
+        // tail path, and the dword-store layout, simply drain.)
+        if (c == 0 || !WIDE || !full_frames)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            wait_vmcnt_at_most(pend_stores);
+#ifndef SRX_X_NOBARRIER
+        __syncthreads();                                  // ... everybody's; and everybody is done with the other buffer
+#endif
+        if (c + 1 < nchunks) dma(c + 1, (c + 1) & 1);
+        pend_stores = 0;
+        typedef const __attribute__((address_space(3))) unsigned char *lds_cptr;
+        const lds_cptr lds3 = (lds_cptr)lds16;
+        const unsigned cb = (c & 1) * CHUNK_BYTES + lane * 16;   // LDS byte offset of this lane's 16 bytes of the chunk's first fragment
+        const int nt = (tile_hi - tile_lo - c * NT) < NT ? (tile_hi - tile_lo - c * NT) : NT;   // even
+        // fragment s of the tile at LDS offset `off`; storage order is [hi 0..KS) [lo 0..KS), the lo fragments are needed first
+        auto frag = [&](unsigned off, int n) __attribute__((always_inline)) {
+            const int s = n < KS ? KS + n : n - KS;
+            return *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(lds3 + off + s * 1024);
+        };
+        // One row tile: its MFMAs (fragments Afc) write `acc` while the epilogue of the previous tile reads `accp` and the
+        // fragments of the next tile are fetched into Afn, one ds_read_b128 per MFMA gap (their address passes through a
+        // pin, which keeps each read in its gap).  After the last tile of a chunk the fetch reads past the chunk -- still
+        // inside this workgroup's LDS (the other chunk buffer or the staging area) -- and is not used: the first tile of
+        // a chunk is read again after the barrier.
+        auto do_tile = [&](int tt, f32x16 (&acc)[FT_PER_WAVE], const f32x16 (&accp)[FT_PER_WAVE], const f16x8 (&Afc)[KS2],
+                           f16x8 (&Afn)[KS2]) __attribute__((always_inline)) {
+            unsigned nxt = cb + (tt + 1) * TILE_BYTES;
+            // small terms first: a_lo b_hi, then a_hi b_lo, then a_hi b_hi
+            static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int p = i / (KS * FT_PER_WAVE), s_ = (i / FT_PER_WAVE) % KS, f = i % FT_PER_WAVE;
+                const f16x8 a_ = p == 0 ? Afc[KS + s_] : Afc[s_];
+                const f16x8 b_ = p == 1 ? Bf[f][KS + s_] : Bf[f][s_];
+#ifdef SRX_X_NOMFMA
+                if (i < FT_PER_WAVE) { acc[f] = z; acc[f][0] = a_[0] + b_[0]; }
+                asm volatile("" : "+v"(acc[f]));
+#else
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, i < FT_PER_WAVE ? z : acc[f], 0, 0, 0);
+#endif
+                // (from gap 1 on: a read placed ahead of the tile's first MFMA would be caught by the wait on Afc there)
+                if constexpr (i >= 1 && i <= KS2) {
+                    asm volatile("" : "+v"(nxt));
+                    Afn[i - 1 < KS ? KS + i - 1 : i - 1 - KS] = frag(nxt, i - 1);
+                }
+#ifdef SRX_X_NOEPI
+                if (i == NMF - 1) { asm volatile("" ::"v"(acc[0])); asm volatile("" ::"v"(acc[1])); }
+#else
+                epi_slice(ic, accp);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (WIDE && tile_prev >= 0 && (tile_prev - tile_lo) % GT == GT - 1) flush_group(tile_prev - tile_lo);
+            tile_prev = tile_lo + c * NT + tt;
+        };
+        f16x8 AfA[KS2], AfB[KS2];
+#pragma unroll
+        for (int n = 0; n < KS2; n++) AfA[n < KS ? KS + n : n - KS] = frag(cb, n);
+        __builtin_amdgcn_sched_barrier(0);
+        // row tiles in pairs, so that the two accumulator sets (and fragment sets) swap roles without register copies
+        for (int tt = 0; tt < nt; tt += 2) {
+            do_tile(tt, accA, accB, AfA, AfB);
+            do_tile(tt + 1, accB, accA, AfB, AfA);
+        }
     }
+    // drain: the epilogue of the last tile (the second of a pair: accB), and the (possibly partial) last group
+    static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) { epi_slice(ic, accB); });
+    if (WIDE) flush_group(tile_prev - tile_lo);
 }
 
 template <int MP, int KS>
-static int launch_f16(srx_ctx *ctx, srx_model *m, const f16x8 *Bp, int64_t T, int64_t nfb, float *out, int64_t st_t, int64_t st_g) {
-    const size_t lds_bytes = (size_t)2 * NT16 * 2 * KS * 1024;
+static int launch_f16(srx_ctx *ctx, srx_model *m, const f16x8 *Bp, int64_t T, int64_t nfb, float *out, int64_t st_t, int64_t st_g,
+                      float *dump) {
+    typedef F16Cfg<MP> Cfg;
+    const size_t lds_bytes = (size_t)2 * Cfg::NT * 2 * KS * 1024 + (size_t)NW16 * Cfg::STAGE_FLOATS * sizeof(float);
+    SRX_REQUIRE(ctx, lds_bytes <= 160 * 1024, "srx_gmm_score: LDS budget exceeded (%zu bytes)", lds_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_f16<MP, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_f16<MP, KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_f16<MP, KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;
-    const int tps = (ntiles + NSLICE - 1) / NSLICE;
+    constexpr int TQ = Cfg::GT > 2 ? Cfg::GT : 2;   // a slice holds whole output groups and whole pairs of row tiles
+    static_assert(Cfg::NT % 2 == 0 && TQ % Cfg::GT == 0 && TQ % 2 == 0, "chunks and slices hold whole tile pairs");
+    const int tps = ((ntiles + NSLICE - 1) / NSLICE + TQ - 1) / TQ * TQ;
     SRX_REQUIRE(ctx, nfb * NSLICE < (1ll << 31), "srx_gmm_score: too many frames for one launch");
     {
         SrxProf prof_(ctx, "k_gmm_f16");
-        hipLaunchKernelGGL((k_gmm_f16<MP, KS>), dim3((unsigned)(nfb * NSLICE)), dim3(64 * NW16), lds_bytes, ctx->stream, Bp, T,
-                           (const f16x8 *)m->packed16, ntiles, tps, m->G, out, st_t, st_g);
+        if (st_t == 1)
+            hipLaunchKernelGGL((k_gmm_f16<MP, KS, true>), dim3((unsigned)(nfb * NSLICE)), dim3(64 * NW16), lds_bytes, ctx->stream, Bp, T,
+                               (const f16x8 *)m->packed16, ntiles, tps, m->G, out, st_t, st_g, dump);
+        else
+            hipLaunchKernelGGL((k_gmm_f16<MP, KS, false>), dim3((unsigned)(nfb * NSLICE)), dim3(64 * NW16), lds_bytes, ctx->stream, Bp, T,
+                               (const f16x8 *)m->packed16, ntiles, tps, m->G, out, st_t, st_g, dump);
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
@@ -397,13 +582,13 @@ static int launch_f16(srx_ctx *ctx, srx_model *m, const f16x8 *Bp, int64_t T, in
 
 template <int KS>
 static int dispatch_mp16(srx_ctx *ctx, srx_model *m, int MP, const f16x8 *Bp, int64_t T, int64_t nfb, float *out, int64_t st_t,
-                         int64_t st_g) {
+                         int64_t st_g, float *dump) {
     switch (MP) {
-        case 1: return launch_f16<1, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
-        case 2: return launch_f16<2, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
-        case 4: return launch_f16<4, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
-        case 8: return launch_f16<8, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
-        case 16: return launch_f16<16, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g);
+        case 1: return launch_f16<1, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g, dump);
+        case 2: return launch_f16<2, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g, dump);
+        case 4: return launch_f16<4, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g, dump);
+        case 8: return launch_f16<8, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g, dump);
+        case 16: return launch_f16<16, KS>(ctx, m, Bp, T, nfb, out, st_t, st_g, dump);
     }
     return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "srx_gmm_score: unsupported component count");
 }
@@ -426,10 +611,12 @@ int srx_gmm_score_f16x3(srx_ctx *ctx, srx_model *m, int mix_mode, const float *f
     const int64_t nft = nfb * NW16 * FT_PER_WAVE;
     const size_t b_bytes = (size_t)nft * 2 * KS * 1024;
     void *ws = nullptr;
-    rc = srx_workspace(ctx, 0, b_bytes + (size_t)T + 256, &ws);
+    const size_t flag_bytes = ((size_t)T + 255) / 256 * 256;
+    rc = srx_workspace(ctx, 0, b_bytes + flag_bytes + 256, &ws);
     if (rc != SRX_OK) return rc;
     f16x8 *Bp = reinterpret_cast<f16x8 *>(ws);
     unsigned char *fflag = reinterpret_cast<unsigned char *>(ws) + b_bytes;
+    float *dump = reinterpret_cast<float *>(fflag + flag_bytes);   // 64 floats for the stores of lanes with nothing to write
     SRX_HIP(ctx, hipMemsetAsync(fflag, 0, (size_t)T, ctx->stream));
     const int64_t n = nft * 2 * KS * 64;
     SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_gmm_score: too many frames");
@@ -439,7 +626,8 @@ int srx_gmm_score_f16x3(srx_ctx *ctx, srx_model *m, int mix_mode, const float *f
                            Bp, fflag);
     }
     SRX_LAUNCH_CHECK(ctx);
-    rc = KS == 2 ? dispatch_mp16<2>(ctx, m, MP, Bp, T, nfb, out, st_t, st_g) : dispatch_mp16<5>(ctx, m, MP, Bp, T, nfb, out, st_t, st_g);
+    rc = KS == 2 ? dispatch_mp16<2>(ctx, m, MP, Bp, T, nfb, out, st_t, st_g, dump)
+                 : dispatch_mp16<5>(ctx, m, MP, Bp, T, nfb, out, st_t, st_g, dump);
     if (rc != SRX_OK) return rc;
     {
         SrxProf prof_(ctx, "k_gmm_fixup16");
