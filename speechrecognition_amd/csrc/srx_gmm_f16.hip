@@ -33,12 +33,13 @@
 #include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int NW16 = 8;          // waves per workgroup
 static constexpr int FT_PER_WAVE = 2;   // 32-frame tiles a wave keeps in registers
 static constexpr int FRAMES_PER_WG = NW16 * FT_PER_WAVE * 32;
-static constexpr int NT16 = 6;          // row tiles per LDS chunk
+static constexpr int NT16 = 8;          // padding row tiles after the last slice (>= one LDS chunk + one unrolled step)
 static constexpr int NSLICE = 8;        // row slices = XCDs
 static constexpr float kLn2f = 0.69314718055994530942f;
 static constexpr float kPadConst = -30000.0f;  // constant of a padded component: 2^-30000 = 0, representable in f16
@@ -282,7 +283,8 @@ struct F16Cfg {
     static constexpr int SPT = 32 / MP;                       // states per row tile
     static constexpr int GT = SPT >= 8 ? 1 : 8 / SPT;         // row tiles per output group (a group = a multiple of 8 states)
     static constexpr int RG = SPT * GT;                       // states (staging rows) per group
-    static constexpr int NT = MP == 1 ? 4 : 6;                // row tiles per LDS chunk
+    static constexpr int U = GT > 2 ? GT : 2;                 // row tiles per unrolled step: whole output groups, whole accumulator pairs
+    static constexpr int NT = 4;                              // row tiles per LDS chunk (a multiple of U)
     static constexpr int STAGE_FLOATS = FT_PER_WAVE * RG * 32;  // per wave
 };
 
@@ -322,19 +324,29 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
     constexpr int TILE_BYTES = KS2 * 1024;
     constexpr int CHUNK_BYTES = NT * TILE_BYTES;
     constexpr int NPIECE = NT * KS2;             // 1 KiB DMA pieces per chunk
-    constexpr int NST = Cfg::NST, SPT = Cfg::SPT, GT = Cfg::GT, RG = Cfg::RG;
+    constexpr int NST = Cfg::NST, SPT = Cfg::SPT, GT = Cfg::GT, RG = Cfg::RG, U = Cfg::U;
+    static_assert(NT % U == 0 && U % GT == 0 && U % 2 == 0, "chunks hold whole unrolled steps");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int slice = blockIdx.x % NSLICE;
     const int64_t fb = blockIdx.x / NSLICE;
     const int tile_lo = slice * tps;
-    // tps is even: a slice holds whole pairs of row tiles.  A pair may end one tile past ntiles; that tile is padding in
-    // A' (states >= G, never stored).
-    const int tile_hi = tile_lo + tps < ntiles + (ntiles & 1) ? tile_lo + tps : ntiles + (ntiles & 1);
+    // tps is a multiple of U, and a slice ends on a multiple of U: its last step may run up to U-1 tiles past ntiles; those
+    // are padding in A' (states >= G, never stored).
+    const int ntiles_r = (ntiles + U - 1) / U * U;
+    const int tile_hi = tile_lo + tps < ntiles_r ? tile_lo + tps : ntiles_r;
     if (tile_lo >= tile_hi) return;
     const int nchunks = (tile_hi - tile_lo + NT - 1) / NT;
-    float *stage = reinterpret_cast<float *>(lds16 + 2 * CHUNK_BYTES) + w * Cfg::STAGE_FLOATS;  // [FT][RG][32]
+    // LDS addressing by integer byte offset through an address-space-3 pointer.  (Reads through a pointer the compiler
+    // can trace to the LDS allocation get an s_waitcnt vmcnt(0) in front of them while an LDS-DMA is outstanding -- that
+    // also drains every global store of the wave.  The DMA is ordered by hand below: counted vmcnt + barrier.)
+    typedef __attribute__((address_space(3))) unsigned char *lds_ptr;
+    const lds_ptr lds3 = (lds_ptr)lds16;
+    constexpr unsigned STAGE_BASE = 2 * CHUNK_BYTES;             // staging area, per wave [FT][RG][32] floats
+    const unsigned stage_w = STAGE_BASE + w * Cfg::STAGE_FLOATS * 4;
+    const unsigned stage_wr = stage_w + ((h * NST) * 32 + j) * 4;               // this lane's column, row h*NST
+    const unsigned stage_rd = stage_w + ((lane >> 3) * 32 + (lane & 7) * 4) * 4;  // row lane/8, four frames from 4*(lane%8)
 
     auto dma = [&](int chunk, int buf) __attribute__((always_inline)) {
         // NPIECE contiguous KiB of A' -> LDS buffer `buf`; piece p is issued by wave p % NW16
@@ -370,20 +382,20 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
     // two accumulator sets that swap roles from tile to tile (no register copies): one is written by the MFMAs of the
     // current tile while the epilogue consumes the other
     f32x16 accA[FT_PER_WAVE], accB[FT_PER_WAVE];
-    int tile_prev = -1;         // tile whose results await their epilogue (-1: none yet)
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int f = 0; f < FT_PER_WAVE; f++) accA[f] = accB[f] = z;
     float mx[FT_PER_WAVE][NST], sum[FT_PER_WAVE][NST];
     int pend_stores = 0;        // store instructions issued since the last DMA issue (wave-uniform)
 
-    // slice `i` (compile-time after unrolling) of the epilogue of the tile whose accumulators are in accp.
+    // Slice `i` of the epilogue of the tile whose accumulators are in accp; `pr` = that tile's position in its output
+    // group; tile_p = its index (non-WIDE only; < 0: none).  i and pr are compile-time, so every range is a constant.
     // pin(): an empty asm the value passes through.  The arithmetic of a slice is pure, so instruction selection would
     // otherwise place it wherever it likes (it clustered all 32 v_sub/v_exp between two MFMAs); with its inputs pinned at
     // the start of the slice and its results at the end, each slice stays between its two MFMAs.
     auto pin = [](float &x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
-    auto epi_slice = [&](auto ic, const f32x16 (&accp)[FT_PER_WAVE]) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;   // compile-time, so that every range below is a constant
+    auto epi_slice = [&](auto ic, auto prc, const f32x16 (&accp)[FT_PER_WAVE], int tile_p) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, pr = decltype(prc)::value;
         if constexpr (i < N1) {
             if constexpr (MP > 1) {
                 constexpr int f0 = i * FT_PER_WAVE / N1, f1 = (i + 1) * FT_PER_WAVE / N1;
@@ -404,20 +416,25 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
         } else if constexpr (i < N1 + N2) {
             if constexpr (MP > 1) {
                 constexpr int e0 = (i - N1) * NEL / N2, e1 = (i - N1 + 1) * NEL / N2;
+                float d_[e1 - e0 + 1];
+                // all differences, then all exponentials, then the sums: no instruction waits on the one before it
 #pragma unroll
                 for (int e = e0; e < e1; e++) {
-                    const int f = e / 16, r = e % 16;
-                    float a_ = accp[f][r];
+                    float a_ = accp[e / 16][e % 16];
                     pin(a_);
-                    float s_ = sum[f][r / MP] + __builtin_amdgcn_exp2f(a_ - mx[f][r / MP]);
-                    pin(s_);
-                    sum[f][r / MP] = s_;
+                    d_[e - e0] = a_ - mx[e / 16][(e % 16) / MP];
                 }
+#pragma unroll
+                for (int e = e0; e < e1; e++) d_[e - e0] = __builtin_amdgcn_exp2f(d_[e - e0]);
+#pragma unroll
+                for (int e = e0; e < e1; e++) sum[e / 16][(e % 16) / MP] += d_[e - e0];
+#pragma unroll
+                for (int e = e0; e < e1; e++)
+                    if (e == e1 - 1 || (e + 1) / MP != e / MP) pin(sum[e / 16][(e % 16) / MP]);
             }
         } else {
             constexpr int k = i - N1 - N2;
             constexpr int f0 = k * FT_PER_WAVE / N3, f1 = (k + 1) * FT_PER_WAVE / N3;
-            const int tl = tile_prev < 0 ? 0 : tile_prev - tile_lo;   // slice-local tile index
 #pragma unroll
             for (int f = f0; f < f1; f++) {
 #pragma unroll
@@ -432,14 +449,15 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
                     }
                     pin(v);
                     if (WIDE) {
-                        // staging row = state within the group
-                        stage[(f * RG + (tl % GT) * SPT + h * NST + st) * 32 + j] = v;
+                        // staging row = state within the group; the offset is an immediate of the ds_write
+                        *reinterpret_cast<__attribute__((address_space(3))) float *>(lds3 + stage_wr +
+                                                                                      ((f * RG + pr * SPT + st) * 32) * 4) = v;
                     } else {
                         const int64_t fr = (ft0 + f) * 32 + j;
-                        const int g = tile_prev * SPT + h * NST + st;
+                        const int g = tile_p * SPT + h * NST + st;
                         // branch-free (a conditional store would split the basic block and undo the interleave):
                         // lanes with nothing to write store to a dump slot
-                        float *dst = (tile_prev >= 0 && fr < T && g < G) ? out + fr * st_t + (int64_t)g * st_g : dump + lane;
+                        float *dst = (tile_p >= 0 && fr < T && g < G) ? out + fr * st_t + (int64_t)g * st_g : dump + lane;
                         *dst = v;
                     }
                 }
@@ -447,35 +465,40 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
         }
     };
 
-    // WIDE: write the staged group that ends with slice-local tile `tl_last` (ntl tiles of it are valid)
-    auto flush_group = [&](int tl_last) __attribute__((always_inline)) {
-        const int gfirst = (tile_lo + tl_last / GT * GT) * SPT;      // first state of the group
-        const int nrows = (tl_last % GT + 1) * SPT;                  // staged rows that hold results
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the wave's staging writes have been issued and retired
+    // WIDE: write the staged output group whose first state is gfirst: per instruction 8 states x 32 frames, a lane stores
+    // four consecutive frames of one state (global_store_dwordx4; 4-byte alignment is enough for it, which the compiler
+    // does not assume -- it splits a float4 store into x3 + x1).
+    float *const out_lane = out + (int64_t)(lane >> 3) * st_g + ft0 * 32 + (lane & 7) * 4;
+    auto flush_group = [&](int gfirst) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < FT_PER_WAVE; f++)
 #pragma unroll
             for (int b = 0; b < RG / 8; b++) {
-                const int row = b * 8 + (lane >> 3);
-                const int fq = (lane & 7) * 4;
-                const float4 v = *reinterpret_cast<const float4 *>(stage + (f * RG + row) * 32 + fq);
-                const int g = gfirst + row;
-                const int64_t fr = (ft0 + f) * 32 + fq;
-                float *dst = out + (int64_t)g * st_g + fr;
-                if (row < nrows && g < G) {
+                const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(lds3 + stage_rd + ((f * RG + b * 8) * 32) * 4);
+                const int g = gfirst + b * 8 + (lane >> 3);
+                float *dst = out_lane + ((int64_t)(gfirst + b * 8) * st_g + f * 32);
+                if (g < G) {
                     if (full_frames) {
-                        *reinterpret_cast<float4 *>(dst) = v;
+                        asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
                     } else {
-                        if (fr < T) dst[0] = v.x;
-                        if (fr + 1 < T) dst[1] = v.y;
-                        if (fr + 2 < T) dst[2] = v.z;
-                        if (fr + 3 < T) dst[3] = v.w;
+                        const int64_t fr = (ft0 + f) * 32 + (lane & 7) * 4;
+                        if (fr < T) dst[0] = v[0];
+                        if (fr + 1 < T) dst[1] = v[1];
+                        if (fr + 2 < T) dst[2] = v[2];
+                        if (fr + 3 < T) dst[3] = v[3];
                     }
                 }
             }
         pend_stores += FT_PER_WAVE * (RG / 8);
     };
 
+    // fragment n (in order of use: lo 0..KS-1, then hi 0..KS-1; storage order is hi first) of the tile at LDS offset `off`
+    auto frag = [&](unsigned off, int n) __attribute__((always_inline)) {
+        const int s = n < KS ? KS + n : n - KS;
+        return *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(lds3 + off + s * 1024);
+    };
+
+    f16x8 AfA[KS2], AfB[KS2];
     for (int c = 0; c < nchunks; c++) {
         // This wave's DMA pieces of chunk c must have landed.  In flight, oldest first: [pieces of chunk c][the stores
         // issued since those pieces were issued].  vmcnt retires in order, so waiting until at most that many operations
@@ -485,27 +508,20 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
             wait_vmcnt_at_most(pend_stores);
-#ifndef SRX_X_NOBARRIER
         __syncthreads();                                  // ... everybody's; and everybody is done with the other buffer
-#endif
         if (c + 1 < nchunks) dma(c + 1, (c + 1) & 1);
         pend_stores = 0;
-        typedef const __attribute__((address_space(3))) unsigned char *lds_cptr;
-        const lds_cptr lds3 = (lds_cptr)lds16;
         const unsigned cb = (c & 1) * CHUNK_BYTES + lane * 16;   // LDS byte offset of this lane's 16 bytes of the chunk's first fragment
-        const int nt = (tile_hi - tile_lo - c * NT) < NT ? (tile_hi - tile_lo - c * NT) : NT;   // even
-        // fragment s of the tile at LDS offset `off`; storage order is [hi 0..KS) [lo 0..KS), the lo fragments are needed first
-        auto frag = [&](unsigned off, int n) __attribute__((always_inline)) {
-            const int s = n < KS ? KS + n : n - KS;
-            return *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>(lds3 + off + s * 1024);
-        };
-        // One row tile: its MFMAs (fragments Afc) write `acc` while the epilogue of the previous tile reads `accp` and the
-        // fragments of the next tile are fetched into Afn, one ds_read_b128 per MFMA gap (their address passes through a
-        // pin, which keeps each read in its gap).  After the last tile of a chunk the fetch reads past the chunk -- still
-        // inside this workgroup's LDS (the other chunk buffer or the staging area) -- and is not used: the first tile of
-        // a chunk is read again after the barrier.
-        auto do_tile = [&](int tt, f32x16 (&acc)[FT_PER_WAVE], const f32x16 (&accp)[FT_PER_WAVE], const f16x8 (&Afc)[KS2],
+        const int nt = (tile_hi - tile_lo - c * NT) < NT ? (tile_hi - tile_lo - c * NT) : NT;   // a multiple of U
+        // One row tile (position u in its unrolled step): its MFMAs (fragments Afc) write `acc` while the epilogue of the
+        // previous tile reads `accp` and the fragments of the next tile are fetched into Afn, one ds_read_b128 per MFMA gap
+        // (their address passes through a pin, which keeps each read in its gap).  After the last tile of a chunk the
+        // fetch reads past the chunk -- still inside this workgroup's LDS (the other chunk buffer or the staging area) --
+        // and is not used: the first tile of a chunk is read again after the barrier.
+        auto do_tile = [&](auto uc, int tt, f32x16 (&acc)[FT_PER_WAVE], const f32x16 (&accp)[FT_PER_WAVE], const f16x8 (&Afc)[KS2],
                            f16x8 (&Afn)[KS2]) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const int tl = c * NT + tt;                   // slice-local index of this tile
             unsigned nxt = cb + (tt + 1) * TILE_BYTES;
             // small terms first: a_lo b_hi, then a_hi b_lo, then a_hi b_hi
             static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) {
@@ -513,40 +529,38 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
                 constexpr int p = i / (KS * FT_PER_WAVE), s_ = (i / FT_PER_WAVE) % KS, f = i % FT_PER_WAVE;
                 const f16x8 a_ = p == 0 ? Afc[KS + s_] : Afc[s_];
                 const f16x8 b_ = p == 1 ? Bf[f][KS + s_] : Bf[f][s_];
-#ifdef SRX_X_NOMFMA
-                if (i < FT_PER_WAVE) { acc[f] = z; acc[f][0] = a_[0] + b_[0]; }
-                asm volatile("" : "+v"(acc[f]));
-#else
                 acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, i < FT_PER_WAVE ? z : acc[f], 0, 0, 0);
-#endif
                 // (from gap 1 on: a read placed ahead of the tile's first MFMA would be caught by the wait on Afc there)
                 if constexpr (i >= 1 && i <= KS2) {
                     asm volatile("" : "+v"(nxt));
                     Afn[i - 1 < KS ? KS + i - 1 : i - 1 - KS] = frag(nxt, i - 1);
                 }
-#ifdef SRX_X_NOEPI
-                if (i == NMF - 1) { asm volatile("" ::"v"(acc[0])); asm volatile("" ::"v"(acc[1])); }
-#else
-                epi_slice(ic, accp);
-#endif
+                epi_slice(ic, std::integral_constant<int, (u + U - 1) % GT>{}, accp, tile_lo + tl - 1 < tile_lo ? -1 : tile_lo + tl - 1);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if (WIDE && tile_prev >= 0 && (tile_prev - tile_lo) % GT == GT - 1) flush_group(tile_prev - tile_lo);
-            tile_prev = tile_lo + c * NT + tt;
+            // the previous tile closed an output group
+            if constexpr (WIDE && u % GT == 0)
+                if (tl > 0) flush_group((tile_lo + tl - GT) * SPT);
         };
-        f16x8 AfA[KS2], AfB[KS2];
 #pragma unroll
         for (int n = 0; n < KS2; n++) AfA[n < KS ? KS + n : n - KS] = frag(cb, n);
         __builtin_amdgcn_sched_barrier(0);
-        // row tiles in pairs, so that the two accumulator sets (and fragment sets) swap roles without register copies
-        for (int tt = 0; tt < nt; tt += 2) {
-            do_tile(tt, accA, accB, AfA, AfB);
-            do_tile(tt + 1, accB, accA, AfB, AfA);
-        }
+        // U row tiles per step: the two accumulator sets (and fragment sets) swap roles without register copies, and the
+        // position of a tile in its output group is a constant
+        for (int tt = 0; tt < nt; tt += U)
+            static_for16(std::make_integer_sequence<int, U>{}, [&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr (u % 2 == 0)
+                    do_tile(uc, tt + u, accA, accB, AfA, AfB);
+                else
+                    do_tile(uc, tt + u, accB, accA, AfB, AfA);
+            });
     }
-    // drain: the epilogue of the last tile (the second of a pair: accB), and the (possibly partial) last group
-    static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) { epi_slice(ic, accB); });
-    if (WIDE) flush_group(tile_prev - tile_lo);
+    // drain: the epilogue of the last tile (odd position: accB), which closes the last group
+    static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) {
+        epi_slice(ic, std::integral_constant<int, GT - 1>{}, accB, tile_hi - 1);
+    });
+    if (WIDE) flush_group((tile_hi - GT) * SPT);
 }
 
 template <int MP, int KS>
@@ -563,8 +577,7 @@ static int launch_f16(srx_ctx *ctx, srx_model *m, const f16x8 *Bp, int64_t T, in
     }
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;
-    constexpr int TQ = Cfg::GT > 2 ? Cfg::GT : 2;   // a slice holds whole output groups and whole pairs of row tiles
-    static_assert(Cfg::NT % 2 == 0 && TQ % Cfg::GT == 0 && TQ % 2 == 0, "chunks and slices hold whole tile pairs");
+    constexpr int TQ = Cfg::U;   // a slice holds whole unrolled steps (output groups, accumulator pairs)
     const int tps = ((ntiles + NSLICE - 1) / NSLICE + TQ - 1) / TQ * TQ;
     SRX_REQUIRE(ctx, nfb * NSLICE < (1ll << 31), "srx_gmm_score: too many frames for one launch");
     {

@@ -46,7 +46,7 @@ def main():
     feats = (rng.standard_normal((T, D)) * 1.3).astype(np.float32)
     model_np = synth.random_model(G, M, D, 777)
     for p in args:
-        res, chk = run(os.path.abspath(p), feats, model_np, T, G, M, D, 5, score_path)
+        res, chk = run(os.path.abspath(p), feats, model_np, T, G, M, D, int(os.environ.get("SRX_REPS", "5")), score_path)
         print("%-28s %s checksum %.4f" % (os.path.basename(p), " ".join("%s %.3f ms" % kv for kv in res.items()), chk), flush=True)
 
 
