@@ -30,6 +30,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def base_name(kernel):
     k = kernel.strip()
+    m = re.match(r"^_Z(\d+)", k)     # a mangled name rocprofv3 left as it was (templates over _Float16 vectors)
+    if m:
+        n = int(m.group(1))
+        return k[m.end():m.end() + n]
     k = re.sub(r"^void\s+", "", k)
     return re.split(r"[<(]", k, maxsplit=1)[0].strip()
 
