@@ -144,6 +144,7 @@ def main():
     from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3
     score_path = SRX_SCORE_MFMA_F16X3 if args.score_path == "f16x3" else SRX_SCORE_MFMA
     gmm_kernel, gmm_prep = ("k_gmm_f16", "k_prep16") if args.score_path == "f16x3" else ("k_gmm_mfma", "k_gmm_prep")
+    mfcc_kernel = "k_mfcc_f16" if args.score_path == "f16x3" else "k_mfcc_tile"
     stream = torch.cuda.Stream()   # a real (non-null) stream: libsrx launches on it and the events below time it
     torch.cuda.set_stream(stream)
     ctx = host.Context(local, stream.cuda_stream)
@@ -152,7 +153,7 @@ def main():
     x, soff, ntrs, trs, tieds = build_workload(args.utts, seed=1 + rank)
     fb, _ = host.mel_filterbank(FEND, NFILT, WL, SPS)
     cfg = host.mfcc_config(WL, HOP, NCEPS)
-    plan = host.MfccPlan(ctx, cfg, fb)
+    plan = host.MfccPlan(ctx, cfg, fb, host.MFCC_F16X3 if args.score_path == "f16x3" else host.MFCC_F32)
     foff = host.frame_offsets(cfg, soff)
     T = int(foff[-1])
     n_utt = args.utts
@@ -205,7 +206,7 @@ def main():
             stage_ms[name] += e[k].elapsed_time(e[k + 1]) / args.steps
 
     kernel_ms = {}
-    for k in ("k_sumsq_scale", "k_mfcc_tile", "k_features", gmm_prep, gmm_kernel, "k_viterbi"):
+    for k in ("k_sumsq_scale", mfcc_kernel, "k_features", gmm_prep, gmm_kernel, "k_viterbi"):
         ms, n = ctx.profile_query(k)
         assert n == args.steps, (k, n)
         kernel_ms[k] = ms / n
@@ -230,7 +231,7 @@ def main():
         f16 = args.score_path == "f16x3"
         gmm_peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
         mfcc_bytes = (HOP * 4 + NCEPS * 4) * T               # 692 B/frame
-        mfcc_ms, vit_ms = kernel_ms["k_mfcc_tile"], kernel_ms["k_viterbi"]
+        mfcc_ms, vit_ms = kernel_ms[mfcc_kernel], kernel_ms["k_viterbi"]
         vit_S = float(np.mean([len(n) for n in ntrs]))
         vit_bytes = (4.25 * vit_S + 5) * T
         out = {
@@ -255,9 +256,9 @@ def main():
                          "vs_f32_mfma_peak": gmm_tflops / PEAK_F32_MFMA_TFLOPS},
             "stages_ms": stage_ms, "kernels_ms": kernel_ms,
             "stage_rooflines": {
-                "mfcc_hbm": {"kernel": "k_mfcc_tile", "achieved_GBs": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9,
+                "mfcc_hbm": {"kernel": mfcc_kernel, "achieved_GBs": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9,
                              "peak_GBs": PEAK_HBM_GBS, "frac": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                             "bytes_per_frame": 692, "traffic": pmc_traffic("k_mfcc_tile", T)},
+                             "bytes_per_frame": 692, "traffic": pmc_traffic(mfcc_kernel, T)},
                 "viterbi_hbm": {"kernel": "k_viterbi", "achieved_GBs": vit_bytes / (vit_ms * 1e-3) / 1e9,
                                 "peak_GBs": PEAK_HBM_GBS, "frac": vit_bytes / (vit_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "bytes_per_frame": 4.25 * vit_S + 5, "traffic": pmc_traffic("k_viterbi", T)},

@@ -99,6 +99,12 @@ int srx_mfcc_plan_create(srx_ctx *ctx, const srx_mfcc_cfg *cfg, const srx_filter
                          srx_mfcc_plan **out);
 void srx_mfcc_plan_destroy(srx_mfcc_plan *plan);
 int srx_mfcc_plan_bin_max(const srx_mfcc_plan *plan);
+/* Which matrix-core formulation srx_mfcc_batch* runs (same reference code replaced, same 1e-4 bar):
+ * SRX_MFCC_F16X3: operands split into two f16 parts, three products on the f16 matrix cores (half windows of 160
+ * or 200 samples, i.e. the reference's 320 and BASELINE's 400-sample windows); SRX_MFCC_F32: f32 matrix cores, any
+ * window; SRX_MFCC_AUTO (default): F16X3 where it applies.  No counterpart in the reference (a tuning knob). */
+enum { SRX_MFCC_AUTO = 0, SRX_MFCC_F32 = 1, SRX_MFCC_F16X3 = 2 };
+int srx_mfcc_plan_set_path(srx_mfcc_plan *plan, int path);
 
 /* Frame count of the do/while(window.slide()) loop, src/mfcc.cpp:261-271 + src/clip.cpp:108-112:
  * n = 1 + floor((L - wl - 1)/hop) for L > wl.  Fills frame_off[n_utt+1] (prefix sums) from

@@ -63,6 +63,7 @@ SIGNATURES = {
     "srx_mfcc_plan_create": (C.c_int, [vp, C.POINTER(srx_mfcc_cfg), C.POINTER(srx_filter), C.c_int, C.POINTER(vp)]),
     "srx_mfcc_plan_destroy": (None, [vp]),
     "srx_mfcc_plan_bin_max": (C.c_int, [vp]),
+    "srx_mfcc_plan_set_path": (C.c_int, [vp, C.c_int]),
     "srx_mfcc_frame_offsets": (C.c_int, [C.POINTER(srx_mfcc_cfg), vp, C.c_int, vp]),
     "srx_mfcc_batch_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]),
     "srx_mfcc_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp]),

@@ -16,27 +16,11 @@
 // against the [N/2][2*NB] cos|sin table streamed through LDS in 32-row chunks.
 #include <cmath>
 
-#include "srx_common.h"
+#include "srx_mfcc_plan.h"
 
 float srx_filter_get(const srx_filter &f, int bin);  // srx_ctx.hip
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct srx_mfcc_plan {
-    srx_ctx *ctx = nullptr;
-    srx_mfcc_cfg cfg;
-    int nfilt = 0, bin_max = 0;
-    int half = 0;   // N/2 live samples per frame
-    int KH = 0;     // half rounded up to a multiple of 4 (MFMA k-step)
-    int NB = 0;     // bins rounded up to a multiple of 64 (groups of 4 tiles)
-    int NFP = 0;    // filters rounded up to 16
-    int NCP = 16;   // cepstra rounded up to 16
-    float rootn_inv = 0;
-    float *win = nullptr;   // [KH]
-    float *twid = nullptr;  // [KH][2][NB]   cos then sin, frequency index already mirrored
-    float *fbm = nullptr;   // [NB][NFP]
-    float *dctm = nullptr;  // [NFP][NCP]
-};
 
 // ------------------------------------------------------------------------------------------
 // K1: per-utterance sum of squares (f32 square, f64 accumulate) and gain target/rms.
@@ -348,12 +332,31 @@ extern "C" int srx_mfcc_plan_create(srx_ctx *ctx, const srx_mfcc_cfg *cfg, const
         srx_mfcc_plan_destroy(p);
         return srx_fail(ctx, SRX_ERR_DEVICE, "srx_mfcc_plan_create: table upload failed: %s", hipGetErrorString(e));
     }
+    if (srx_mfcc16_supported(p->half, n_filters, cfg->n_ceps, bin_max)) {
+        int rc = srx_mfcc16_build(p, win, tw, fbm, dm);
+        if (rc != SRX_OK) {
+            srx_mfcc_plan_destroy(p);
+            return rc;
+        }
+    }
     *out = p;
+    return SRX_OK;
+}
+
+extern "C" int srx_mfcc_plan_set_path(srx_mfcc_plan *p, int path) {
+    if (!p) return SRX_ERR_INVALID;
+    SRX_REQUIRE(p->ctx, path == SRX_MFCC_AUTO || path == SRX_MFCC_F32 || path == SRX_MFCC_F16X3, "srx_mfcc_plan_set_path: unknown path %d", path);
+    SRX_REQUIRE(p->ctx, path != SRX_MFCC_F16X3 || p->ks16 > 0,
+                "srx_mfcc_plan_set_path: the split-f16 path covers half windows of 145..160 or 193..208 samples, <= 64 filters, <= 256 bins");
+    p->path = path;
     return SRX_OK;
 }
 
 extern "C" void srx_mfcc_plan_destroy(srx_mfcc_plan *p) {
     if (!p) return;
+    (void)hipFree(p->win16);
+    (void)hipFree(p->pk16);
+    (void)hipFree(p->dct16);
     (void)hipFree(p->win);
     (void)hipFree(p->twid);
     (void)hipFree(p->fbm);
@@ -386,6 +389,9 @@ extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const
         }
         SRX_LAUNCH_CHECK(ctx);
     }
+    if (plan->ks16 > 0 && plan->path != SRX_MFCC_F32)
+        return srx_mfcc16_launch(ctx, plan, samples_dev, sample_off_dev, n_utt, frame_off_dev, total_frames,
+                                 c.normalize ? scratch_scale_dev : nullptr, ceps_dev);
     MfccArgs a;
     a.x = samples_dev; a.soff = sample_off_dev; a.foff = frame_off_dev;
     a.scale = c.normalize ? scratch_scale_dev : nullptr;

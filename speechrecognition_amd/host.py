@@ -140,8 +140,11 @@ def frame_offsets(cfg, sample_off):
     return fo
 
 
+MFCC_AUTO, MFCC_F32, MFCC_F16X3 = 0, 1, 2
+
+
 class MfccPlan:
-    def __init__(self, ctx, cfg, fb):
+    def __init__(self, ctx, cfg, fb, path=MFCC_AUTO):
         self.ctx, self.cfg = ctx, cfg
         fb = np.ascontiguousarray(fb, dtype=FILTER_DT)
         h = C.c_void_p()
@@ -149,6 +152,11 @@ class MfccPlan:
                                            C.byref(h)), ctx.h)
         self.h = h
         self.bin_max = ctx.lib.srx_mfcc_plan_bin_max(h)
+        if path != MFCC_AUTO:
+            self.set_path(path)
+
+    def set_path(self, path):
+        check(self.ctx.lib.srx_mfcc_plan_set_path(self.h, path), self.ctx.h)
 
     def close(self):
         if self.h:

