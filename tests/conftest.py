@@ -15,6 +15,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def ctx():
     """One srx context on cuda:0.  Fails loudly (no skip, no fallback) when libsrx cannot run."""
+    import torch
+    torch.cuda.init()     # before libsrx touches the device: torch's HIP runtime does not come up after another one
     from speechrecognition_amd import host
     c = host.Context(0)
     yield c

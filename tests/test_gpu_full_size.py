@@ -1,0 +1,224 @@
+"""BASELINE.json configs 1-5 at their full sizes (config 5 at the size one GPU holds densely), checked through
+size-independent properties plus oracle spot checks on random samples:
+
+  config 1  1,000-utterance MFCC batch: split-f16 path == f32 path (1e-4 of the frame's cepstral scale) on every frame,
+            oracle on sampled utterances
+  config 2  GMM scoring 2,000 x 16 x 39 over 1,048,576 frames: split-f16 == f32 matrix-core path on all 2.1e9 scores,
+            oracle (long double) on sampled frames, position independence (a copied frame scores bit-identically)
+  config 3  forced alignment of 10,000 utterances: every path starts one transition from state 0, ends in the last state, moves by
+            0/1/2 states and only skips where the topology has the skip; oracle (bit-exact path and score) on samples
+  config 4  one embedded-training iteration on 10,000 utterances (5e6 frames, dense 40 GB emission matrix): the gathered
+            tied ids equal the paths' states, visited states keep weights summing to 1 and positive variances, the model
+            of sampled states equals the oracle's statistics restricted to the frames aligned to them
+
+torch is used as device-memory plumbing only (allocation, gathers, comparisons on the GPU)."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA, host, synth
+from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3
+
+pytestmark = pytest.mark.gpu
+
+G, M, D = 2000, 16, 39
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _tensor(ctx, shape, dtype):
+    """A torch CUDA tensor and a DevArray view of the same memory."""
+    torch = _torch()
+    tdt = {np.float32: torch.float32, np.int32: torch.int32}[dtype]
+    t = torch.empty(shape, dtype=tdt, device=torch.device("cuda", ctx.device))
+    return t, host.DevArray.wrap(ctx, t.data_ptr(), tuple(shape), dtype, t)
+
+
+def test_config1_mfcc_1000_utterances(ctx, oracle):
+    torch = _torch()
+    x, soff = synth.corpus_audio(1000, seed=1)
+    fb, _ = host.mel_filterbank(7200, 48, 400, 16000)
+    cfg = host.mfcc_config(400, 160)
+    foff = host.frame_offsets(cfg, soff)
+    T, n = int(foff[-1]), 1000
+    assert 400_000 < T < 600_000
+    x_d, soff_d, foff_d = ctx.array(x), ctx.array(soff), ctx.array(foff)
+    scale_d = ctx.empty((n,), np.float32)
+    outs = {}
+    for path in (host.MFCC_F16X3, host.MFCC_F32):
+        plan = host.MfccPlan(ctx, cfg, fb, path)
+        t, d = _tensor(ctx, (T, 13), np.float32)
+        plan.write_features_dev(x_d, soff_d, n, foff_d, T, scale_d, d)
+        ctx.sync()
+        outs[path] = t
+        plan.close()
+    a, b = outs[host.MFCC_F16X3], outs[host.MFCC_F32]
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    scale = b.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert float(((a - b).abs() / scale).max()) <= 1e-4
+    rng = np.random.default_rng(0)
+    for u in rng.choice(n, 3, replace=False):
+        xu = oracle.normalize_volume(x[soff[u]:soff[u + 1]])
+        ref, _ = oracle.write_features(xu, 400, 160, fb, 13)
+        got = a[int(foff[u]):int(foff[u + 1])].cpu().numpy()
+        s = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-30)
+        assert (np.abs(got - ref) / s).max() <= 1e-4
+
+
+def test_config2_gmm_scoring_1M_frames(ctx, oracle):
+    torch = _torch()
+    T = 1_048_576
+    rng = np.random.default_rng(777)
+    feats = (rng.standard_normal((T, D), dtype=np.float32) * np.float32(1.3)).astype(np.float32)
+    dup_src, dup_dst = np.arange(1000, 1500), np.arange(T - 777, T - 277)     # copies at other tile positions
+    feats[dup_dst] = feats[dup_src]
+    mean, var, w = synth.random_model(G, M, D, 777)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    feats_d = ctx.array(feats)
+    ta, da = _tensor(ctx, (G, T), np.float32)     # state-major, as the alignment kernel reads it
+    tb, db = _tensor(ctx, (G, T), np.float32)
+    model.score_dev(feats_d, D, T, da, 1, T, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3)
+    model.score_dev(feats_d, D, T, db, 1, T, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA)
+    ctx.sync()
+    assert bool(torch.isfinite(ta).all())
+    worst = 0.0
+    for g0 in range(0, G, 250):                    # in slabs: keeps the temporaries at 1 GB
+        a, b = ta[g0:g0 + 250], tb[g0:g0 + 250]
+        worst = max(worst, float(((a - b).abs() / b.abs().clamp_min(1.0)).max()))
+    assert worst <= 1e-4, worst
+    # position independence: the same frame scores bit-identically wherever it sits
+    ia = torch.as_tensor(dup_src, device=ta.device)
+    ib = torch.as_tensor(dup_dst, device=ta.device)
+    assert torch.equal(ta.index_select(1, ia), ta.index_select(1, ib))
+    # oracle on sampled frames, all 2,000 states
+    idx = np.sort(rng.choice(T, 24, replace=False))
+    got = ta.index_select(1, torch.as_tensor(idx, device=ta.device)).T.cpu().numpy()
+    f39 = np.zeros((len(idx), 39), np.float32)
+    f39[:, :D] = feats[idx]
+    ref = oracle.gmm_score(f39, mean, var, oracle.set_wt(w), D, SRX_MIX_LOGSUMEXP)
+    assert (np.abs(got - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)).all(), np.abs(got - ref).max()
+    model.close()
+
+
+def _alignment_corpus(n_utt, seed):
+    rng = np.random.default_rng(seed)
+    ntrs, trs, tieds, Ts = [], [], [], []
+    for _ in range(n_utt):
+        ph = synth.phone_string(rng, int(rng.integers(4, 13)))
+        ntr, tr, _ = host.build_training_hmm(ph)
+        ntrs.append(ntr)
+        trs.append(tr)
+        tieds.append(rng.integers(0, G, len(ph)).astype(np.int32))
+        Ts.append(int(rng.integers(200, 801)))
+    fo = np.zeros(n_utt + 1, np.int64)
+    fo[1:] = np.cumsum(Ts)
+    return ntrs, trs, tieds, fo
+
+
+def _check_paths(path, status, fo, ntrs):
+    """Topology properties of every alignment (vectorised over the whole batch)."""
+    assert (status == 0).all()
+    first, last = fo[:-1], fo[1:] - 1
+    S = np.array([len(n) for n in ntrs])
+    # frame 0 is reached by a transition out of state 0 (src/hmm.cpp:153-169), so it is state 0, 1 or (over a skip) 2
+    assert ((path[first] >= 0) & (path[first] <= np.where(np.array([n[0] for n in ntrs]) == 3, 2, 1))).all()
+    assert (path[last] == S - 1).all()
+    step = np.diff(path)
+    inner = np.ones(len(path) - 1, bool)
+    inner[last[:-1]] = False                      # differences across utterance boundaries
+    assert ((step[inner] >= 0) & (step[inner] <= 2)).all()
+    # a two-state move needs a source with three transitions
+    ntr_flat = np.concatenate(ntrs)
+    soff = np.concatenate([[0], np.cumsum(S)])[:-1]
+    utt_of = np.repeat(np.arange(len(S)), np.diff(fo))
+    src = path[:-1] + soff[utt_of[:-1]]
+    skip = inner & (step == 2)
+    assert (ntr_flat[src[skip]] == 3).all()
+
+
+def test_config3_alignment_10k_utterances(ctx, oracle):
+    torch = _torch()
+    n = 10_000
+    ntrs, trs, tieds, fo = _alignment_corpus(n, 4)
+    T = int(fo[-1])
+    rng = np.random.default_rng(5)
+    feats = (rng.standard_normal((T, D), dtype=np.float32) * np.float32(1.3)).astype(np.float32)
+    mean, var, w = synth.random_model(G, M, D, 777)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(mean, var, w)
+    te, de = _tensor(ctx, (G, T), np.float32)      # 40 GB
+    model.score_dev(ctx.array(feats), D, T, de, 1, T, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3)
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    path_d, final_d, status_d = hb.viterbi(de, 1, T, 1e10)
+    ctx.sync()
+    path, final, status = path_d.get(), final_d.get(), status_d.get()
+    _check_paths(path, status, fo, ntrs)
+    for u in rng.choice(n, 40, replace=False):
+        e = te[:, int(fo[u]):int(fo[u + 1])].T.contiguous().cpu().numpy()     # the emissions the kernel saw
+        r = oracle.viterbi(e, tieds[u], ntrs[u], trs[u], 1e10, 0)
+        assert r["status"] == 0
+        assert final[u].tobytes() == r["final"].tobytes()
+        assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"])
+    model.close()
+
+
+def test_config4_training_iteration_10k_utterances(ctx, oracle):
+    torch = _torch()
+    n = 10_000
+    ntrs, trs, tieds, fo = _alignment_corpus(n, 6)
+    T = int(fo[-1])
+    rng = np.random.default_rng(7)
+    mean, var, w = synth.random_model(G, M, D, 777)
+    # frames drawn around the states of a plausible alignment, so that components get real occupancy
+    feats = np.zeros((T, D), np.float32)
+    for u in range(n):
+        a, b = int(fo[u]), int(fo[u + 1])
+        st = np.minimum((np.arange(b - a) * len(tieds[u])) // (b - a), len(tieds[u]) - 1)
+        g = tieds[u][st]
+        c = rng.integers(0, M, b - a)
+        feats[a:b] = mean[g, c] + rng.standard_normal((b - a, D)) * np.sqrt(var[g, c])
+    A = host.AcousticModel(ctx, G, M, D)
+    B = host.AcousticModel(ctx, G, M, D)
+    A.set(mean, var, w)
+    B.copy_from(A)
+    feats_d = ctx.array(feats)
+    te, de = _tensor(ctx, (G, T), np.float32)
+    A.score_dev(feats_d, D, T, de, 1, T, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3)
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    path_d, final_d, status_d = hb.viterbi(de, 1, T, 1e10)
+    hb.train_transition_probabilities(path_d, status_d)
+    gid_d = host.gather_gid(ctx, hb, path_d, status_d)
+    stats1, stats2, shift = host.em_statistics(ctx, A, B, feats_d, D, gid_d, T, 0.2)
+    ctx.sync()
+    path, status, gid = path_d.get(), status_d.get(), gid_d.get()
+    _check_paths(path, status, fo, ntrs)
+    # gid is the tied id of the aligned state
+    tied_flat = np.concatenate(tieds)
+    S = np.array([len(t) for t in tieds])
+    soff = np.concatenate([[0], np.cumsum(S)])[:-1]
+    utt_of = np.repeat(np.arange(n), np.diff(fo))
+    assert np.array_equal(gid, tied_flat[path + soff[utt_of]])
+    # (zeta is the raw component density, src/hmm.cpp:280-287, not a posterior: there is no occupancy to conserve;
+    #  what the update guarantees is that a visited state's weights still sum to 1 after the 0.2/0.8 blend)
+    s1 = stats1.get().reshape(G, M, 1 + D)
+    count = np.bincount(gid, minlength=G)
+    gm, gv, gw = B.get()
+    seen = count > 0
+    assert (s1[seen, :, 0] > 0).all() and (s1[~seen, :, 0] == 0).all()
+    assert seen.sum() > 1900
+    np.testing.assert_allclose(gw[seen].sum(axis=1), 1.0, rtol=2e-6)
+    assert (gv[seen] > 0).all() and np.isfinite(gm[seen]).all()
+    # oracle on sampled states: the statistics of a state depend only on the frames aligned to it
+    pick = rng.choice(np.flatnonzero(seen), 6, replace=False)
+    sel = np.isin(gid, pick)
+    f39 = np.zeros((int(sel.sum()), 39), np.float32)
+    f39[:, :D] = feats[sel]
+    rm, rv, rw, _, _ = oracle.em_statistics(f39, gid[sel], D, mean, var, w, 0.2)
+    np.testing.assert_allclose(gm[pick], rm[pick].astype(np.float64), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gv[pick], rv[pick].astype(np.float64), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gw[pick], rw[pick], rtol=3e-7)
+    A.close()
+    B.close()
