@@ -77,13 +77,14 @@ void pack_features(const vector<featurevec *> &fvs, vector<float> &out) {
 
 // gmm::operator() as written returns component 0 (src/gmm.cpp:99-100); SRX_MIX=logsumexp selects the
 // commented-out intent.  SRX_SCORE_PATH=exact selects the per-dimension evaluation in the reference's
-// operation order instead of the MFMA contraction.
+// operation order instead of the MFMA contraction; SRX_SCORE_PATH=f16x3 the split-f16 contraction (fastest).
 int env_choice(const char *name, const char *alt, int dflt, int other) {
     const char *v = std::getenv(name);
     return (v && !std::strcmp(v, alt)) ? other : dflt;
 }
 int g_mix_mode = env_choice("SRX_MIX", "logsumexp", SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP);
-int g_score_path = env_choice("SRX_SCORE_PATH", "exact", SRX_SCORE_MFMA, SRX_SCORE_EXACT);
+int g_score_path = env_choice("SRX_SCORE_PATH", "f16x3", env_choice("SRX_SCORE_PATH", "exact", SRX_SCORE_MFMA, SRX_SCORE_EXACT),
+                              SRX_SCORE_MFMA_F16X3);
 
 }  // namespace
 
