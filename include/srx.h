@@ -211,6 +211,24 @@ typedef struct {
 int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
                           int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
 
+/* Alignment-mode emission scoring: every utterance's frames against that utterance's own states only -- what the
+ * reference computes lazily inside hmm::viterbi (src/hmm.cpp:166, (*acm)(*fvs[i], target->ctx) for the targets of the
+ * active states) -- instead of the dense [T][G] matrix of srx_gmm_score_dev.  The plan (host frame/state offsets of the
+ * batch) fixes the compact layout: utterance u owns emis[off[u] .. off[u+1]) as a state-major block [S_u][T_u],
+ * off[u+1] - off[u] = S_u * T_u.  Scores are bit-identical to srx_gmm_score_dev's on the same path.
+ * score_path: SRX_SCORE_MFMA_F16X3 (models f16 cannot hold are evaluated exactly instead) or SRX_SCORE_EXACT. */
+typedef struct srx_align_plan srx_align_plan;
+int srx_align_plan_create(srx_ctx *ctx, const int64_t *frame_off, const int32_t *state_off, int n_utt, srx_align_plan **out);
+void srx_align_plan_destroy(srx_align_plan *plan);
+int64_t srx_align_plan_emission_count(const srx_align_plan *plan);             /* floats: off[n_utt] */
+int srx_align_plan_emission_offsets(const srx_align_plan *plan, int64_t *off); /* host copy, [n_utt+1] */
+const int64_t *srx_align_plan_emission_offsets_dev(const srx_align_plan *plan);
+int srx_gmm_score_align_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
+                            const srx_hmm_batch *hmm, const srx_align_plan *plan, float *emis_dev);
+/* srx_viterbi_batch_dev on the compact emissions of srx_gmm_score_align_dev (same kernel, same bit-exactness). */
+int srx_viterbi_align_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const srx_align_plan *plan, const float *emis_dev,
+                          float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
+
 /* hmm::train_transition_probabilities  src/hmm.cpp:229-243 (+ set/get_adv_prob :26-35) for every
  * utterance whose status is 0. */
 int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,

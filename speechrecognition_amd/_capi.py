@@ -83,6 +83,13 @@ SIGNATURES = {
     "srx_gmm_score": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp]),
     "srx_hmm_build_training": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "srx_viterbi_batch_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, i64, i64, C.c_float, vp, vp, vp]),
+    "srx_align_plan_create": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(vp)]),
+    "srx_align_plan_destroy": (None, [vp]),
+    "srx_align_plan_emission_count": (C.c_int64, [vp]),
+    "srx_align_plan_emission_offsets": (C.c_int, [vp, vp]),
+    "srx_align_plan_emission_offsets_dev": (vp, [vp]),
+    "srx_gmm_score_align_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(srx_hmm_batch), vp, vp]),
+    "srx_viterbi_align_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, C.c_float, vp, vp, vp]),
     "srx_train_transitions_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp]),
     "srx_state_model_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, vp, C.c_int, vp, vp]),
     "srx_em_gather_gid_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, i64, vp]),

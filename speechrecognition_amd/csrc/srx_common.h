@@ -110,6 +110,10 @@ struct srx_model {
     size_t packed16_bytes = 0;
     uint64_t packed16_version = 0;
     int packed16_mode = -1;
+    void *packed16s = nullptr;     // per-state form for alignment-mode scoring (srx_gmm_f16_align.hip)
+    size_t packed16s_bytes = 0;
+    uint64_t packed16s_version = 0;
+    int packed16s_mode = -1;
     float *colstats = nullptr;     // [3][D]: centre, column scale s_d, 1/s_d
     int *flag16 = nullptr;         // device flag: some coefficient does not fit f16
     bool f16_ok = false;

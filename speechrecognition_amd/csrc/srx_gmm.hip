@@ -49,6 +49,7 @@ extern "C" void srx_model_destroy(srx_model *m) {
     (void)hipFree(m->center);
     (void)hipFree(m->packed);
     (void)hipFree(m->packed16);
+    (void)hipFree(m->packed16s);
     (void)hipFree(m->colstats);
     (void)hipFree(m->flag16);
     delete m;

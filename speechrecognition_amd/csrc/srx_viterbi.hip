@@ -40,7 +40,7 @@ template <int SPL, bool BEAM>
 __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                                 const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
                                                 const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
-                                                float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
+                                                const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
                                                 float *__restrict__ final_logp, int32_t *__restrict__ status) {
     const int u = blockIdx.x;
     if (u >= n_utt) return;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         col[q] = 0;
         act[q] = (s == 0);
         if (s < S) {
-            col[q] = tied[s0 + s];
+            col[q] = ebase ? s : tied[s0 + s];   // compact per-utterance block: the row is the state itself
             a0[q] = trlogp[(size_t)(s0 + s) * 3];
             tv0[q] = dmin[s + 2];
             if (s >= 1 && ntr[s0 + s - 1] >= 2) {
@@ -101,7 +101,12 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         has2[q] = (s < S && s >= 2) ? ntr[s0 + s - 2] == 3 : false;
     }
 
-    const float *erow = emis + f0 * st_t;
+    // dense matrix: frame t of the batch, column tied[s]; compact (alignment-mode scoring): utterance block [S][T] at ebase[u]
+    if (ebase) {
+        st_t = 1;
+        st_g = T;
+    }
+    const float *erow = ebase ? emis + ebase[u] : emis + f0 * st_t;
     int64_t eoff[SPL];
 #pragma unroll
     for (int q = 0; q < SPL; q++) eoff[q] = (int64_t)col[q] * st_g;
@@ -303,8 +308,8 @@ __global__ __launch_bounds__(256) void k_train_transitions(int n_utt, const int6
     }
 }
 
-extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
-                                     int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
+static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t, int64_t stride_g,
+                          const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
     SRX_REQUIRE(nullptr, ctx, "srx_viterbi_batch_dev: null ctx");
     SRX_REQUIRE(ctx, hmm && emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
     SRX_REQUIRE(ctx, hmm->frame_off_dev && hmm->state_off_dev && hmm->tied_dev && hmm->ntr_dev && hmm->trlogp_dev,
@@ -323,7 +328,7 @@ extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
     dim3 grid(hmm->n_utt), block(64);
 #define SRX_VIT(SPLV, BEAMV)                                                                                              \
     hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,            \
-                       hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, beam_width, \
+                       hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, ebase_dev, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
     {
         SrxProf prof_(ctx, "k_viterbi");
@@ -334,6 +339,19 @@ extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
 #undef SRX_VIT
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
+}
+
+extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
+                                     int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
+    return viterbi_launch(ctx, hmm, emis_dev, stride_t, stride_g, nullptr, beam_width, path_dev, final_logp_dev, status_dev);
+}
+
+extern "C" int srx_viterbi_align_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const srx_align_plan *plan, const float *emis_dev,
+                                     float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
+    SRX_REQUIRE(nullptr, ctx, "srx_viterbi_align_dev: null ctx");
+    SRX_REQUIRE(ctx, plan, "srx_viterbi_align_dev: null plan");
+    return viterbi_launch(ctx, hmm, emis_dev, 1, 0, srx_align_plan_emission_offsets_dev(plan), beam_width, path_dev, final_logp_dev,
+                          status_dev);
 }
 
 extern "C" int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,

@@ -329,6 +329,42 @@ class HmmBatch:
     def train_transition_probabilities(self, path_d, status_d):
         check(self.ctx.lib.srx_train_transitions_dev(self.ctx.h, C.byref(self.c), path_d.ptr, status_d.ptr), self.ctx.h)
 
+    # ---- alignment-mode scoring: each utterance against its own states, compact emissions ----
+    def align_plan(self):
+        """Layout of the compact emission buffer (utterance u: state-major block [S_u][T_u] at emis_off[u])."""
+        if getattr(self, "_plan", None) is None:
+            h = C.c_void_p()
+            check(self.ctx.lib.srx_align_plan_create(self.ctx.h, _ptr(self.frame_off), _ptr(self.state_off), self.n_utt, C.byref(h)),
+                  self.ctx.h)
+            self._plan = h
+            self.emis_count = int(self.ctx.lib.srx_align_plan_emission_count(h))
+            self.emis_off = np.zeros(self.n_utt + 1, np.int64)
+            check(self.ctx.lib.srx_align_plan_emission_offsets(h, _ptr(self.emis_off)), self.ctx.h)
+        return self._plan
+
+    def score_align(self, model, feats_d, ld, emis_d=None, mix_mode=SRX_MIX_COMPONENT0, path=None):
+        """(*acm)(fv, ctx) for every frame and every state of the frame's own utterance (src/hmm.cpp:166)."""
+        from ._capi import SRX_SCORE_MFMA_F16X3
+        plan = self.align_plan()
+        emis_d = emis_d or self.ctx.empty((max(self.emis_count, 1),), np.float32)
+        check(self.ctx.lib.srx_gmm_score_align_dev(self.ctx.h, model.h, mix_mode, SRX_SCORE_MFMA_F16X3 if path is None else path,
+                                                   feats_d.ptr, ld, C.byref(self.c), plan, emis_d.ptr), self.ctx.h)
+        return emis_d
+
+    def viterbi_align(self, emis_d, beam=1e10, path_d=None, final_d=None, status_d=None):
+        ctx = self.ctx
+        path_d = path_d or ctx.zeros((max(self.total_frames, 1),), np.int32)
+        final_d = final_d or ctx.zeros((max(self.n_utt, 1),), np.float32)
+        status_d = status_d or ctx.zeros((max(self.n_utt, 1),), np.int32)
+        check(ctx.lib.srx_viterbi_align_dev(ctx.h, C.byref(self.c), self.align_plan(), emis_d.ptr, beam, path_d.ptr, final_d.ptr,
+                                            status_d.ptr), ctx.h)
+        return path_d, final_d, status_d
+
+    def close(self):
+        if getattr(self, "_plan", None) is not None:
+            self.ctx.lib.srx_align_plan_destroy(self._plan)
+            self._plan = None
+
 
 # ----------------------------------------------------------------------------- EM statistics
 def em_statistics(ctx, A, B, feats_d, ld, gid_d, T, blend_keep=0.2, allreduce_max=None, allreduce_sum=None):
