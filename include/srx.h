@@ -251,6 +251,8 @@ int srx_state_model_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *c
  *   3. srx_em_means_dev      weights + means of B from stats1
  *   4. srx_em_pass2_dev      zeta*(x-mean_B)^2 sums     -> stats2[G*M*D] f64     (all-reduce SUM)
  *   5. srx_em_finish_dev     variances of B, then B = keep*B + (1-keep)*A (gaussian::blend)
+ * Call them in this order for every new alignment: step 1 also sorts the frames by state when the table is too
+ * large for LDS (then passes 2 and 4 are atomics-free segmented reductions, deterministic in frame order).
  * zeta is computed as w*exp(logp - shift[g][m]) in f64 (the reference uses unshifted 80-bit values;
  * every quantity it derives from them is a ratio in which the shift cancels or is re-applied). */
 int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,

@@ -18,8 +18,13 @@ struct srx_ctx {
     int num_cus = 256;
     char err[512] = {0};
     // grow-only device workspace (Viterbi back-pointer words, ...)
-    void *ws[2] = {nullptr, nullptr};   // slot 0: GMM operand rows, slot 1: Viterbi back-pointers
-    size_t ws_bytes[2] = {0, 0};
+    // slot 0: GMM operand rows, 1: Viterbi back-pointers, 2: frames sorted by state (EM statistics), 3: EM partial sums
+    void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[4] = {0, 0, 0, 0};
+    // what slot 2 currently holds (srx_train_seg.hip): the alignment it was sorted from
+    const int32_t *em_gid = nullptr;
+    int64_t em_T = -1;
+    int em_G = 0;
     // per-kernel timing (srx_profile_enable / srx_profile_query): event pairs recorded on `stream`
     struct prof_rec {
         const char *name;
@@ -110,6 +115,9 @@ struct srx_model {
     size_t packed16_bytes = 0;
     uint64_t packed16_version = 0;
     int packed16_mode = -1;
+    // frame-independent part of gaussian::operator(): lconst[o][d] = (double)(float)log(2/pi) + log(var[o][d])  (srx_train.hip)
+    double *lconst = nullptr;
+    uint64_t lconst_version = 0;
     void *packed16s = nullptr;     // per-state form for alignment-mode scoring (srx_gmm_f16_align.hip)
     size_t packed16s_bytes = 0;
     uint64_t packed16s_version = 0;
@@ -128,6 +136,21 @@ __device__ __forceinline__ float srx_logprob_exact(const float *__restrict__ fv,
         float t = (float)((double)fv[i] - mean[i]);
         float tt = t * t;
         double term = ((double)l2pi + log(var[i])) + (double)tt / var[i];
+        res = (float)((double)res + term);
+    }
+    float h = -0.5f * res;
+    return h + logwt;
+}
+
+// The same value bit for bit, with the frame-independent sum (l2pi + log(var[i])) taken from a table.
+__device__ __forceinline__ float srx_logprob_exact_lc(const float *__restrict__ fv, const double *__restrict__ mean,
+                                                      const double *__restrict__ var, const double *__restrict__ lconst, float logwt,
+                                                      int D) {
+    float res = 0.0f;
+    for (int i = 0; i < D; i++) {
+        float t = (float)((double)fv[i] - mean[i]);
+        float tt = t * t;
+        double term = lconst[i] + (double)tt / var[i];
         res = (float)((double)res + term);
     }
     float h = -0.5f * res;

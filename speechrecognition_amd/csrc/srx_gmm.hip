@@ -50,6 +50,7 @@ extern "C" void srx_model_destroy(srx_model *m) {
     (void)hipFree(m->packed);
     (void)hipFree(m->packed16);
     (void)hipFree(m->packed16s);
+    (void)hipFree(m->lconst);
     (void)hipFree(m->colstats);
     (void)hipFree(m->flag16);
     delete m;

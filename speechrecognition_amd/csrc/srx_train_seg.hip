@@ -1,0 +1,341 @@
+// Embedded-training statistics as a sort-by-state segmented reduction (tables too large for the LDS-privatised
+// accumulation of srx_train.hip, i.e. BASELINE shapes: G*M = 32,000 rows of 1+D doubles = 10 MB).
+//
+// Replaces the same reference loops as k_em_accum (hmm::train passes, src/hmm.cpp:298-339).  Frames are sorted by
+// tied state once per iteration (stable radix sort: within a state they stay in frame order, so sums are
+// deterministic -- no atomics anywhere); a workgroup then owns up to CH consecutive frames of ONE state and keeps
+// that state's M x (1+D) sums in registers while the frames' zetas and feature rows pass through LDS; states with
+// more than CH frames are split and their partial sums added in chunk order by a second small kernel.
+// At G = 2000, M = 16, D = 39 the HBM-atomics form spends 157 ms per pass on 5e6 frames; this form is bound by
+// reading logp and the feature rows once.
+#include <hipcub/hipcub.hpp>
+
+#include "srx_common.h"
+
+static constexpr int CH = 2048;     // frames per work item
+static constexpr int FB = 32;       // frames staged per step
+static constexpr int ACC_MAX = 4;   // accumulators per thread (256 threads): M*(1+D) <= 1024
+
+struct EmSortView {
+    int32_t *keys_in, *keys_out, *vals_in, *order;   // [T] each; order = frame indices sorted by state
+    int64_t *start;                                  // [G+2] first sorted position of state g; start[G] = aligned frames
+    int32_t *item_start;                             // [G+1] exclusive scan of ceil(n_g / CH)
+};
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+static void em_sort_view(void *base, int64_t T, int G, EmSortView *v) {
+    char *p = reinterpret_cast<char *>(base);
+    v->keys_in = reinterpret_cast<int32_t *>(p);  p += align256((size_t)T * 4);
+    v->keys_out = reinterpret_cast<int32_t *>(p); p += align256((size_t)T * 4);
+    v->vals_in = reinterpret_cast<int32_t *>(p);  p += align256((size_t)T * 4);
+    v->order = reinterpret_cast<int32_t *>(p);    p += align256((size_t)T * 4);
+    v->start = reinterpret_cast<int64_t *>(p);    p += align256((size_t)(G + 2) * 8);
+    v->item_start = reinterpret_cast<int32_t *>(p);
+}
+static size_t em_sort_bytes(int64_t T, int G) { return 4 * align256((size_t)T * 4) + align256((size_t)(G + 2) * 8) + align256((size_t)(G + 2) * 4); }
+
+__global__ __launch_bounds__(256) void k_em_sort_keys(const int32_t *__restrict__ gid, int64_t T, int G, int32_t *__restrict__ keys,
+                                                      int32_t *__restrict__ vals) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int g = gid[t];
+    keys[t] = (g < 0 || g >= G) ? G : g;   // skipped frames sort last
+    vals[t] = (int32_t)t;
+}
+
+// start[g] = first sorted position whose key >= g, g = 0 .. G (start[G] = number of aligned frames)
+__global__ __launch_bounds__(256) void k_em_seg_bounds(const int32_t *__restrict__ keys, int64_t T, int G, int64_t *__restrict__ start) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > G) return;
+    int64_t lo = 0, hi = T;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    start[g] = lo;
+}
+
+// item_start = exclusive scan of ceil(n_g / CH) over states (one block; G is at most a few tens of thousands)
+__global__ __launch_bounds__(1024) void k_em_item_scan(const int64_t *__restrict__ start, int G, int32_t *__restrict__ item_start) {
+    __shared__ int part[1024];
+    const int per = (G + 1023) / 1024;
+    const int g0 = threadIdx.x * per;
+    int s = 0;
+    for (int g = g0; g < g0 + per && g < G; g++) s += (int)((start[g + 1] - start[g] + CH - 1) / CH);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int g = g0; g < g0 + per && g < G; g++) {
+        item_start[g] = run;
+        run += (int)((start[g + 1] - start[g] + CH - 1) / CH);
+    }
+    if (threadIdx.x == 1023) item_start[G] = part[1023];
+}
+
+// One work item = up to CH frames of one state.  PASS 1: sums [zeta, zeta*x_d]; PASS 2: [zeta*diff_d^2],
+// diff = f32(x_d - meanB[o][d]) (src/hmm.cpp:331).  partial[item][M*stride].
+template <int PASS>
+__global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
+                                                      const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
+                                                      int M, int D, const float *__restrict__ weight, const float *__restrict__ logp,
+                                                      const float *__restrict__ shift, const double *__restrict__ meanB,
+                                                      double *__restrict__ partial) {
+    __shared__ double zeta[FB][16];
+    __shared__ float xv[FB][64];
+    __shared__ int ft[FB];
+    const int item = blockIdx.x;
+    if (item >= item_start[G]) return;
+    int lo = 0, hi = G;   // item_start[lo] <= item < item_start[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int g = lo;
+    const int64_t p0 = start[g] + (int64_t)(item - item_start[g]) * CH;
+    const int64_t p1 = p0 + CH < start[g + 1] ? p0 + CH : start[g + 1];
+    const int stride = PASS == 1 ? 1 + D : D;
+    const int R = M * stride;
+    double acc[ACC_MAX];
+    double mb[ACC_MAX];
+    int am[ACC_MAX], ae[ACC_MAX];
+#pragma unroll
+    for (int a = 0; a < ACC_MAX; a++) {
+        const int idx = threadIdx.x + a * 256;
+        acc[a] = 0.0;
+        am[a] = idx < R ? idx / stride : 0;
+        ae[a] = idx < R ? idx % stride : 0;
+        mb[a] = (PASS == 2 && idx < R) ? meanB[((size_t)g * M + am[a]) * D + ae[a]] : 0.0;
+    }
+    for (int64_t p = p0; p < p1; p += FB) {
+        const int nf = p1 - p < FB ? (int)(p1 - p) : FB;
+        __syncthreads();   // the previous step's reads are done
+        if (threadIdx.x < nf) ft[threadIdx.x] = order[p + threadIdx.x];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nf * M; i += 256) {
+            const int f = i / M, m = i - f * M;
+            const size_t o = (size_t)g * M + m;
+            // zeta = weight * prob (src/hmm.cpp:282,307,328), shifted
+            zeta[f][m] = (double)weight[o] * exp((double)logp[(int64_t)ft[f] * M + m] - (double)shift[o]);
+        }
+        for (int i = threadIdx.x; i < nf * D; i += 256) {
+            const int f = i / D, d = i - f * D;
+            xv[f][d] = feats[(int64_t)ft[f] * ld + d];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < ACC_MAX; a++) {
+            if (threadIdx.x + a * 256 < R) {
+                const int m = am[a], e = ae[a];
+                double s = acc[a];
+                if (PASS == 1) {
+                    if (e == 0) {
+                        for (int f = 0; f < nf; f++) s += zeta[f][m];
+                    } else {
+                        for (int f = 0; f < nf; f++) s += zeta[f][m] * (double)xv[f][e - 1];
+                    }
+                } else {
+                    for (int f = 0; f < nf; f++) {
+                        const float diff = (float)((double)xv[f][e] - mb[a]);
+                        s += zeta[f][m] * (double)diff * (double)diff;
+                    }
+                }
+                acc[a] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < ACC_MAX; a++)
+        if (threadIdx.x + a * 256 < R) partial[(size_t)item * R + threadIdx.x + a * 256] = acc[a];
+}
+
+// Log-densities of the aligned frames under A in sorted order: a work item's state parameters sit in LDS and the item's
+// frames stream past them (the frame-order kernel k_em_logp gathers 780 bytes of parameters per (frame, component)
+// through L2).  Same routine, same bits (srx_logprob_exact_lc).  shift[o] = max over the frames of component o.
+__global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
+                                                     const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
+                                                     int M, int D, const double *__restrict__ mean, const double *__restrict__ var,
+                                                     const double *__restrict__ lconst, const float *__restrict__ logwt,
+                                                     float *__restrict__ logp, float *__restrict__ shift) {
+    extern __shared__ double par[];          // mean[M][D], var[M][D], lconst[M][D]
+    __shared__ float xs[16][64];             // 16 frames per step
+    __shared__ int fts[16];
+    __shared__ float smax[16];
+    const int item = blockIdx.x;
+    if (item >= item_start[G]) return;
+    int lo = 0, hi = G;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int g = lo;
+    const int64_t p0 = start[g] + (int64_t)(item - item_start[g]) * CH;
+    const int64_t p1 = p0 + CH < start[g + 1] ? p0 + CH : start[g + 1];
+    const int MD = M * D;
+    double *pm = par, *pv = par + MD, *pl = par + 2 * MD;
+    for (int i = threadIdx.x; i < MD; i += 256) {
+        pm[i] = mean[(size_t)g * MD + i];
+        pv[i] = var[(size_t)g * MD + i];
+        pl[i] = lconst[(size_t)g * MD + i];
+    }
+    if (threadIdx.x < 16) smax[threadIdx.x] = -__builtin_huge_valf();
+    // thread = (frame slot f = tid / 16, component m = tid % 16): 16 frames x 16 components per step
+    const int f = threadIdx.x >> 4, m = threadIdx.x & 15;
+    const float lw = m < M ? logwt[(size_t)g * M + m] : 0.0f;
+    float mymax = -__builtin_huge_valf();
+    for (int64_t p = p0; p < p1; p += 16) {
+        const int nf = p1 - p < 16 ? (int)(p1 - p) : 16;
+        __syncthreads();
+        if (threadIdx.x < nf) fts[threadIdx.x] = order[p + threadIdx.x];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nf * D; i += 256) {
+            const int ff = i / D, d = i - ff * D;
+            xs[ff][d] = feats[(int64_t)fts[ff] * ld + d];
+        }
+        __syncthreads();
+        if (f < nf && m < M) {
+            const float lp = srx_logprob_exact_lc(xs[f], pm + m * D, pv + m * D, pl + m * D, lw, D);
+            logp[(int64_t)fts[f] * M + m] = lp;
+            if (lp == lp) mymax = fmaxf(mymax, lp);
+        }
+    }
+    // per-component maximum of this item -> shift (float max through the ordered-int trick of k_em_logp)
+    __syncthreads();
+    if (m < M && mymax > -__builtin_huge_valf()) {
+        if (mymax >= 0.0f)
+            atomicMax(reinterpret_cast<int *>(&smax[m]), __float_as_int(mymax));
+        else
+            atomicMin(reinterpret_cast<unsigned int *>(&smax[m]), __float_as_uint(mymax));
+    }
+    __syncthreads();
+    if (threadIdx.x < M && smax[threadIdx.x] > -__builtin_huge_valf()) {
+        const float v = smax[threadIdx.x];
+        float *addr = &shift[(size_t)g * M + threadIdx.x];
+        if (v >= 0.0f)
+            atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
+        else
+            atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+    }
+}
+
+// frames that were skipped (gid < 0) get logp = 0 like k_em_logp
+__global__ __launch_bounds__(256) void k_em_logp_skipped(const int32_t *__restrict__ order, const int64_t *__restrict__ start, int G, int64_t T,
+                                                         int M, float *__restrict__ logp) {
+    const int64_t i = start[G] + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    const int64_t t = order[i];
+    for (int m = 0; m < M; m++) logp[t * M + m] = 0.0f;
+}
+
+int srx_em_logp_seg(srx_ctx *ctx, const float *feats, int ld, int64_t T, int G, int M, int D, const double *mean, const double *var,
+                    const double *lconst, const float *logwt, float *logp, float *shift) {
+    EmSortView v;
+    em_sort_view(ctx->ws[2], T, G, &v);
+    const int64_t max_items = T / CH + G + 1;
+    {
+        SrxProf prof_(ctx, "k_em_logp_seg");
+        hipLaunchKernelGGL(k_em_logp_seg, dim3((unsigned)max_items), dim3(256), (size_t)3 * M * D * sizeof(double), ctx->stream, feats, ld, v.order,
+                           v.start, v.item_start, G, M, D, mean, var, lconst, logwt, logp, shift);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    {
+        SrxProf prof_(ctx, "k_em_logp_skipped");
+        hipLaunchKernelGGL(k_em_logp_skipped, dim3((unsigned)ceil_div64(T, 256)), dim3(256), 0, ctx->stream, v.order, v.start, G, T, M, logp);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+// stats[g][.] = sum over the state's items, in chunk order
+__global__ __launch_bounds__(256) void k_em_seg_reduce(const int32_t *__restrict__ item_start, int G, int R, const double *__restrict__ partial,
+                                                       double *__restrict__ stats) {
+    const int g = blockIdx.x;
+    const int i0 = item_start[g], i1 = item_start[g + 1];
+    for (int idx = threadIdx.x; idx < R; idx += 256) {
+        double s = 0.0;
+        for (int it = i0; it < i1; it++) s += partial[(size_t)it * R + idx];
+        stats[(size_t)g * R + idx] = s;
+    }
+}
+
+bool srx_em_seg_applicable(int M, int D) { return M <= 16 && D <= 63 && M * (1 + D) <= 256 * ACC_MAX; }
+
+// Sorts the frames of alignment `gid` by state into workspace slot 2 (kept until the next sort).
+int srx_em_seg_sort(srx_ctx *ctx, const int32_t *gid, int64_t T, int G) {
+    SRX_REQUIRE(ctx, T < (1ll << 31), "srx_em_*: too many frames for one shard (%lld)", (long long)T);
+    void *ws = nullptr;
+    int rc = srx_workspace(ctx, 2, em_sort_bytes(T, G), &ws);
+    if (rc != SRX_OK) return rc;
+    EmSortView v;
+    em_sort_view(ws, T, G, &v);
+    ctx->em_gid = nullptr;
+    {
+        SrxProf prof_(ctx, "k_em_sort_keys");
+        hipLaunchKernelGGL(k_em_sort_keys, dim3((unsigned)ceil_div64(T, 256)), dim3(256), 0, ctx->stream, gid, T, G, v.keys_in, v.vals_in);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    int bits = 1;
+    while ((1ll << bits) <= G) bits++;
+    size_t temp_bytes = 0;
+    SRX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, v.keys_in, v.keys_out, v.vals_in, v.order, (int)T, 0, bits, ctx->stream));
+    void *temp = nullptr;
+    rc = srx_workspace(ctx, 3, temp_bytes, &temp);
+    if (rc != SRX_OK) return rc;
+    {
+        SrxProf prof_(ctx, "em_radix_sort");
+        SRX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, v.keys_in, v.keys_out, v.vals_in, v.order, (int)T, 0, bits, ctx->stream));
+    }
+    {
+        SrxProf prof_(ctx, "k_em_seg_bounds");
+        hipLaunchKernelGGL(k_em_seg_bounds, dim3((G + 1 + 255) / 256), dim3(256), 0, ctx->stream, v.keys_out, T, G, v.start);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    {
+        SrxProf prof_(ctx, "k_em_item_scan");
+        hipLaunchKernelGGL(k_em_item_scan, dim3(1), dim3(1024), 0, ctx->stream, v.start, G, v.item_start);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    ctx->em_gid = gid;
+    ctx->em_T = T;
+    ctx->em_G = G;
+    return SRX_OK;
+}
+
+template <int PASS>
+int srx_em_accum_seg(srx_ctx *ctx, const float *feats, int ld, const int32_t *gid, int64_t T, int G, int M, int D, const float *weight,
+                     const float *logp, const float *shift, const double *meanB, double *stats) {
+    if (ctx->em_gid != gid || ctx->em_T != T || ctx->em_G != G) {   // pass called without the shift step of this alignment
+        int rc = srx_em_seg_sort(ctx, gid, T, G);
+        if (rc != SRX_OK) return rc;
+    }
+    EmSortView v;
+    em_sort_view(ctx->ws[2], T, G, &v);
+    const int R = M * (PASS == 1 ? 1 + D : D);
+    const int64_t max_items = T / CH + G + 1;
+    void *pw = nullptr;
+    int rc = srx_workspace(ctx, 3, (size_t)max_items * R * sizeof(double), &pw);
+    if (rc != SRX_OK) return rc;
+    {
+        SrxProf prof_(ctx, PASS == 1 ? "k_em_accum_seg1" : "k_em_accum_seg2");
+        hipLaunchKernelGGL((k_em_accum_seg<PASS>), dim3((unsigned)max_items), dim3(256), 0, ctx->stream, feats, ld, v.order, v.start,
+                           v.item_start, G, M, D, weight, logp, shift, meanB, (double *)pw);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    {
+        SrxProf prof_(ctx, "k_em_seg_reduce");
+        hipLaunchKernelGGL(k_em_seg_reduce, dim3(G), dim3(256), 0, ctx->stream, v.item_start, G, R, (const double *)pw, stats);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+template int srx_em_accum_seg<1>(srx_ctx *, const float *, int, const int32_t *, int64_t, int, int, int, const float *, const float *,
+                                 const float *, const double *, double *);
+template int srx_em_accum_seg<2>(srx_ctx *, const float *, int, const int32_t *, int64_t, int, int, int, const float *, const float *,
+                                 const float *, const double *, double *);

@@ -56,7 +56,10 @@ class TrainingShard:
     hmm::train (src/hmm.cpp:254-347) over it.  Buffers that are exchanged are torch tensors (so that
     torch.distributed can reduce them in place); libsrx reads and writes them through their data pointers."""
 
-    def __init__(self, ctx, hmm_batch, feats_d, ld, G, M, D, exchange=None, mix_mode=0, score_path=0):
+    def __init__(self, ctx, hmm_batch, feats_d, ld, G, M, D, exchange=None, mix_mode=0, score_path=0, emissions="dense"):
+        """emissions: "dense" = the [G][T] matrix of srx_gmm_score_dev (any score path); "compact" = alignment-mode
+        scoring of each utterance's own states (srx_gmm_score_align_dev: split-f16 or exact path; 40x less scoring
+        work and memory at G = 2000, the only form that holds a 100k-utterance shard)."""
         import torch
         from . import host
         self.torch, self.host = torch, host
@@ -67,7 +70,12 @@ class TrainingShard:
         T = hmm_batch.total_frames
         self.T = T
         dev = torch.device("cuda", ctx.device)
-        self.emis = ctx.empty((G, max(T, 1)), np.float32)          # state-major [G][T]
+        self.emissions = emissions
+        if emissions == "compact":
+            hmm_batch.align_plan()
+            self.emis = ctx.empty((max(hmm_batch.emis_count, 1),), np.float32)   # utterance blocks [S_u][T_u]
+        else:
+            self.emis = ctx.empty((G, max(T, 1)), np.float32)      # state-major [G][T]
         self.path = ctx.zeros((max(T, 1),), np.int32)
         self.final = ctx.zeros((max(hmm_batch.n_utt, 1),), np.float32)
         self.status = ctx.zeros((max(hmm_batch.n_utt, 1),), np.int32)
@@ -98,8 +106,12 @@ class TrainingShard:
         ctx, hb, lib = self.ctx, self.hb, self.ctx.lib
         T = self.T
         if T > 0:
-            vit_model.score_dev(self.feats_d, self.ld, T, self.emis, 1, T, self.mix_mode, self.score_path)
-            hb.viterbi(self.emis, 1, T, 1e10, self.path, self.final, self.status)
+            if self.emissions == "compact":
+                hb.score_align(vit_model, self.feats_d, self.ld, self.emis, self.mix_mode, self.score_path)
+                hb.viterbi_align(self.emis, 1e10, self.path, self.final, self.status)
+            else:
+                vit_model.score_dev(self.feats_d, self.ld, T, self.emis, 1, T, self.mix_mode, self.score_path)
+                hb.viterbi(self.emis, 1, T, 1e10, self.path, self.final, self.status)
             hb.train_transition_probabilities(self.path, self.status)
             check(lib.srx_em_gather_gid_dev(ctx.h, hb.c_ref(), self.path.ptr, self.status.ptr, T, self.gid.ptr), ctx.h)
         check(lib.srx_em_shift_dev(ctx.h, A.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr, self.shift.ptr), ctx.h)
