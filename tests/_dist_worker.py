@@ -89,7 +89,8 @@ def main():
         O.set(mean, var, w)
         Cm.copy_from(O)
         shard = parallel.TrainingShard(ctx, hb, ctx.array(x) if len(x) else ctx.zeros((1, feats.shape[1]), np.float32),
-                                       feats.shape[1], G, M, D, ex, int(z["mix_mode"]), 1)
+                                       feats.shape[1], G, M, D, ex, int(z["mix_mode"]), 1,
+                                       emissions=str(z["emissions"]) if "emissions" in z.files else "dense")
         A, B = O, Cm
         for _ in range(int(z["iters"])):
             shard.iteration(O, A, B, 0.2)     # Viterbi always under O

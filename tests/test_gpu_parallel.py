@@ -11,8 +11,8 @@ from tests.test_parallel_cpu import run_world
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,mix_mode", [(1, 0), (2, 1)])
-def test_training_iteration_world2_matches_single_process_oracle(oracle, tmp_path, M, mix_mode):
+@pytest.mark.parametrize("M,mix_mode,emissions", [(1, 0, "dense"), (2, 1, "dense"), (2, 1, "compact")])
+def test_training_iteration_world2_matches_single_process_oracle(oracle, tmp_path, M, mix_mode, emissions):
     rng = np.random.default_rng(21 + M)
     G, D, iters = 40, 13, 2
     n_utt = 7
@@ -29,7 +29,7 @@ def test_training_iteration_world2_matches_single_process_oracle(oracle, tmp_pat
         g = phones[u][seg]
         feats[frame_off[u]:frame_off[u + 1], :D] = (mean[g, 0] + rng.standard_normal((lens[u], D)) * 1.2).astype(np.float32)
     np.savez(tmp_path / "in.npz", shape=[G, M, D], mean=mean, var=var, w=w, feats=feats, frame_off=frame_off, iters=iters,
-             mix_mode=mix_mode, **{"ph%d" % u: phones[u] for u in range(n_utt)})
+             mix_mode=mix_mode, emissions=emissions, **{"ph%d" % u: phones[u] for u in range(n_utt)})
     outs = run_world("gpu", tmp_path, 2)
     assert sorted(np.concatenate([o["mine"] for o in outs]).tolist()) == list(range(n_utt))
     assert all(len(o["mine"]) > 0 for o in outs)
