@@ -328,10 +328,17 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
                 for (int f = f0; f < f1; f++) {
 #pragma unroll
                     for (int st = 0; st < NST; st++) {
+                        // v_max3 directly: fmaxf() on MFMA results gets a canonicalising v_max in front of every operand
                         float m_ = accp[f][st * MP];
                         pin(m_);
+                        if constexpr (MP == 2) {
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + 1]));
+                        } else {
 #pragma unroll
-                        for (int q = 1; q < MP; q++) m_ = fmaxf(m_, accp[f][st * MP + q]);
+                            for (int q = 1; q + 1 < MP; q += 2)
+                                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + q]), "v"(accp[f][st * MP + q + 1]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + MP - 1]));
+                        }
                         pin(m_);
                         mx[f][st] = m_;
                         sum[f][st] = 0.0f;
