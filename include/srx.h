@@ -214,8 +214,8 @@ int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
 /* Alignment-mode emission scoring: every utterance's frames against that utterance's own states only -- what the
  * reference computes lazily inside hmm::viterbi (src/hmm.cpp:166, (*acm)(*fvs[i], target->ctx) for the targets of the
  * active states) -- instead of the dense [T][G] matrix of srx_gmm_score_dev.  The plan (host frame/state offsets of the
- * batch) fixes the compact layout: utterance u owns emis[off[u] .. off[u+1]) as a state-major block [S_u][T_u],
- * off[u+1] - off[u] = S_u * T_u.  Scores are bit-identical to srx_gmm_score_dev's on the same path.
+ * batch) fixes the compact layout: utterance u owns emis[off[u] .. off[u+1]) as a frame-major block [T_u][S_u]
+ * (emis[off[u] + t*S_u + s]), off[u+1] - off[u] = S_u * T_u.  Scores are bit-identical to srx_gmm_score_dev's on the same path.
  * score_path: SRX_SCORE_MFMA_F16X3 (models f16 cannot hold are evaluated exactly instead) or SRX_SCORE_EXACT. */
 typedef struct srx_align_plan srx_align_plan;
 int srx_align_plan_create(srx_ctx *ctx, const int64_t *frame_off, const int32_t *state_off, int n_utt, srx_align_plan **out);

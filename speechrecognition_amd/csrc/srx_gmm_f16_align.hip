@@ -8,7 +8,8 @@
 // walks that utterance's row tiles; the A' fragments of a tile are gathered per lane from a per-state table
 // [G][k-step][component][k-half] straight into registers one tile ahead (no LDS, no barriers: waves are independent,
 // the table of an utterance's ~50 states is a few hundred KB of L2 hits), and the wave builds its own B' fragments from
-// the feature rows (nobody else needs them).  Output: per utterance a state-major block [S_u][T_u] at emis_off[u].
+// the feature rows (nobody else needs them).  Output: per utterance a frame-major block [T_u][S_u] at emis_off[u] (one or two cache lines per frame for the
+// Viterbi wave that reads it), staged per wave through LDS in slabs of 64 frames x 16 states.
 #include "srx_gmm_f16.h"
 
 struct srx_align_plan {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gmm_exact_align(const unsigned char *__
                 }
                 r = (float)log(acc);
             }
-            ob[(int64_t)s * T + lf] = r;
+            ob[(int64_t)lf * S + s] = r;
         }
     }
 }
@@ -189,8 +190,13 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     typedef F16Cfg<MP> Cfg;
     constexpr int KS2 = 2 * KS;
     constexpr int NST = Cfg::NST, SPT = Cfg::SPT;
+    constexpr int SB = SPT > 16 ? SPT : 16;     // states per output slab
+    constexpr int TPS = SB / SPT;               // row tiles per slab
+    constexpr int LDR = SB + 1;                 // staging row stride (odd: the transposing writes spread over the banks)
+    __shared__ float stage_all[NWA][64 * LDR];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *const stage = stage_all[w];          // [64 frames][SB states] of this wave
     const int64_t wb = (int64_t)blockIdx.x * NWA + w;
     if (wb >= n_wb) return;
     const int u = wb_utt[wb], lf0 = wb_f0[wb];
@@ -296,14 +302,26 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
                         v = (mx[f][st] + __builtin_amdgcn_logf(s_)) * kLn2f;
                     }
                     pin(v);
-                    const int lf = lf0 + f * 32 + j;
-                    const int sl = tp * SPT + hh * NST + st;
-                    // branch-free: lanes with nothing to write store to a dump slot
-                    float *dst = (tp >= 0 && lf < T && sl < S) ? ob + (int64_t)sl * T + lf : dump + lane;
-                    *dst = v;
+                    // staging row = frame, column = state within the slab (a tile before the first writes a column that
+                    // the first real tile overwrites)
+                    const int tq = tp < 0 ? 0 : tp % TPS;
+                    stage[(f * 32 + j) * LDR + tq * SPT + hh * NST + st] = v;
                 }
             }
         }
+    };
+    // writes slab `sb` (states sb*SB ..): 64 lanes walk the [64][SB] block row-major, so a row's SB states leave as one
+    // contiguous segment of the frame-major output
+    auto flush_slab = [&](int sb) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 4
+        for (int e = lane; e < 64 * SB; e += 64) {
+            const int f = e / SB, c = e % SB;
+            const int lf = lf0 + f, sl = sb * SB + c;
+            const float v = stage[f * LDR + c];
+            if (lf < T && sl < S) ob[(int64_t)lf * S + sl] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
     // One row tile n: MFMAs on fragments Afc into `acc`; the epilogue of tile n-1 reads `accp`; the fragments of tile n+1
@@ -328,6 +346,7 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
             __builtin_amdgcn_sched_barrier(0);
         });
         g1 = g2;
+        if (n >= 1 && (n - 1) % TPS == TPS - 1) flush_slab((n - 1) / TPS);   // tile n-1 closed a slab
     };
     f16x8 AfA[KS2], AfB[KS2];
     {
@@ -340,6 +359,7 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
         do_tile(n + 1, accB, accA, AfB, AfA);
     }
     static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) { epi_slice(ic, accB, ntile_r - 1); });
+    flush_slab((ntile_r - 1) / TPS);   // the slab the last tile belongs to
 }
 
 template <int MP, int KS>

@@ -101,10 +101,11 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         has2[q] = (s < S && s >= 2) ? ntr[s0 + s - 2] == 3 : false;
     }
 
-    // dense matrix: frame t of the batch, column tied[s]; compact (alignment-mode scoring): utterance block [S][T] at ebase[u]
+    // dense matrix: frame t of the batch, column tied[s]; compact (alignment-mode scoring): utterance block [T][S] at
+    // ebase[u] -- a frame's emissions are one contiguous row, one or two cache lines per wave load
     if (ebase) {
-        st_t = 1;
-        st_g = T;
+        st_t = S;
+        st_g = 1;
     }
     const float *erow = ebase ? emis + ebase[u] : emis + f0 * st_t;
     int64_t eoff[SPL];

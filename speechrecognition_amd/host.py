@@ -331,7 +331,7 @@ class HmmBatch:
 
     # ---- alignment-mode scoring: each utterance against its own states, compact emissions ----
     def align_plan(self):
-        """Layout of the compact emission buffer (utterance u: state-major block [S_u][T_u] at emis_off[u])."""
+        """Layout of the compact emission buffer (utterance u: frame-major block [T_u][S_u] at emis_off[u])."""
         if getattr(self, "_plan", None) is None:
             h = C.c_void_p()
             check(self.ctx.lib.srx_align_plan_create(self.ctx.h, _ptr(self.frame_off), _ptr(self.state_off), self.n_utt, C.byref(h)),

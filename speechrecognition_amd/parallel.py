@@ -73,7 +73,7 @@ class TrainingShard:
         self.emissions = emissions
         if emissions == "compact":
             hmm_batch.align_plan()
-            self.emis = ctx.empty((max(hmm_batch.emis_count, 1),), np.float32)   # utterance blocks [S_u][T_u]
+            self.emis = ctx.empty((max(hmm_batch.emis_count, 1),), np.float32)   # utterance blocks [T_u][S_u]
         else:
             self.emis = ctx.empty((G, max(T, 1)), np.float32)      # state-major [G][T]
         self.path = ctx.zeros((max(T, 1),), np.int32)

@@ -27,11 +27,11 @@ def _batch(rng, n_utt, G, t_lo, t_hi, words=None):
 
 
 def _compact_from_dense(dense, hb, tieds):
-    """dense [T, G] -> the compact layout (utterance u: [S_u][T_u] at emis_off[u])."""
+    """dense [T, G] -> the compact layout (utterance u: [T_u][S_u] at emis_off[u])."""
     out = np.empty(hb.emis_count, np.float32)
     for u in range(hb.n_utt):
         a, b = int(hb.frame_off[u]), int(hb.frame_off[u + 1])
-        blk = dense[a:b][:, tieds[u]].T            # [S_u, T_u]
+        blk = dense[a:b][:, tieds[u]]              # [T_u, S_u]
         out[hb.emis_off[u]:hb.emis_off[u + 1]] = blk.ravel()
     return out
 
@@ -59,7 +59,7 @@ def test_align_scores_equal_dense_scores_bitwise(ctx, oracle, G, M, D, mode):
     lw = oracle.set_wt(w)
     for u in (0, 7):
         a, b = int(fo[u]), int(fo[u + 1])
-        o = oracle.gmm_score(feats[a:b], mean, var, lw, D, mode)[:, tieds[u]].T.ravel()
+        o = oracle.gmm_score(feats[a:b], mean, var, lw, D, mode)[:, tieds[u]].ravel()
         g = got[hb.emis_off[u]:hb.emis_off[u + 1]]
         fin = np.isfinite(o)                     # the outlier frame underflows to -inf in the reference too
         assert np.array_equal(g[~fin], o[~fin])
@@ -113,7 +113,7 @@ def test_viterbi_on_compact_emissions_matches_dense(ctx, oracle):
     ec = emis_c.get()
     for u in (0, 11, 59):
         S, Tu = len(tieds[u]), int(fo[u + 1] - fo[u])
-        e = ec[hb.emis_off[u]:hb.emis_off[u + 1]].reshape(S, Tu).T.copy()    # [T_u, S_u], column = state
+        e = ec[hb.emis_off[u]:hb.emis_off[u + 1]].reshape(Tu, S).copy()      # [T_u, S_u], column = state
         r = oracle.viterbi(e, np.arange(S, dtype=np.int32), ntrs[u], trs[u], 1e10, 0)
         assert r["status"] == 0 and f1.get()[u].tobytes() == r["final"].tobytes()
         assert np.array_equal(p1.get()[fo[u]:fo[u + 1]], r["path"])
