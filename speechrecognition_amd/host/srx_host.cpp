@@ -849,15 +849,29 @@ void hmm::train(vector<utterance> &ut, int iterations) {
     // swaps acm / temp_acm each iteration (src/hmm.cpp:344-346): Viterbi runs under the utterances' model
     acoustic_model *vit_model = ut[0].hmm->acm;
     const int G = vit_model->num_states(), M = acm->num_mix();
-    Dev<float> d_e((size_t)T * G), d_final((size_t)b.c.n_utt), d_logp((size_t)T * M), d_shift((size_t)G * M);
+    // Emissions: the split-f16 and exact score paths look up only each utterance's own states, as hmm::viterbi does
+    // (src/hmm.cpp:166), into compact per-utterance blocks; the f32 matrix-core path fills the dense [G][T] matrix.
+    struct PlanGuard {
+        srx_align_plan *p = nullptr;
+        ~PlanGuard() { srx_align_plan_destroy(p); }
+    } plan;
+    const bool compact = g_score_path != SRX_SCORE_MFMA;
+    if (compact) check(srx_align_plan_create(ctx, b.foff.data(), b.soff.data(), b.c.n_utt, &plan.p));
+    const size_t n_emis = compact ? (size_t)srx_align_plan_emission_count(plan.p) : (size_t)T * G;
+    Dev<float> d_e(n_emis ? n_emis : 1), d_final((size_t)b.c.n_utt), d_logp((size_t)T * M), d_shift((size_t)G * M);
     Dev<int32_t> d_path((size_t)T), d_status((size_t)b.c.n_utt), d_gid((size_t)T);
     Dev<double> d_s1((size_t)G * M * (1 + FV_LEN)), d_s2((size_t)G * M * FV_LEN);
     vector<float> prevp(ut.size(), 0.0f);
     for (int it = 1; it <= iterations; it++) {
         if (srx::verbose()) std::cout << "----------------------Iteration " << it << "-------------------------" << std::endl;
         // Viterbi paths for each utterance (src/hmm.cpp:257-267), emissions state-major [G][T]
-        check(srx_gmm_score_dev(ctx, vit_model->device(), g_mix_mode, g_score_path, d_x.p, ld, T, d_e.p, 1, T));
-        check(srx_viterbi_batch_dev(ctx, &b.c, d_e.p, 1, T, 1e10f, d_path.p, d_final.p, d_status.p));
+        if (compact) {
+            check(srx_gmm_score_align_dev(ctx, vit_model->device(), g_mix_mode, g_score_path, d_x.p, ld, &b.c, plan.p, d_e.p));
+            check(srx_viterbi_align_dev(ctx, &b.c, plan.p, d_e.p, 1e10f, d_path.p, d_final.p, d_status.p));
+        } else {
+            check(srx_gmm_score_dev(ctx, vit_model->device(), g_mix_mode, g_score_path, d_x.p, ld, T, d_e.p, 1, T));
+            check(srx_viterbi_batch_dev(ctx, &b.c, d_e.p, 1, T, 1e10f, d_path.p, d_final.p, d_status.p));
+        }
         if (srx::verbose()) {
             vector<float> fin = d_final.get();
             vector<int32_t> st = d_status.get();
