@@ -41,7 +41,7 @@ def main():
     if args and args[0] == "--path":
         score_path = int(args[1])
         args = args[2:]
-    T, G, M, D = int(os.environ.get("SRX_T", "499674")), 2000, 16, 39
+    T, G, M, D = int(os.environ.get("SRX_T", "499674")), int(os.environ.get("SRX_G", "2000")), 16, 39
     rng = np.random.default_rng(0)
     feats = (rng.standard_normal((T, D)) * 1.3).astype(np.float32)
     model_np = synth.random_model(G, M, D, 777)
