@@ -165,9 +165,11 @@ def main():
     scale_d = ctx.empty((n_utt,), np.float32)
     ceps_d = ctx.empty((T, NCEPS), np.float32)
     feats_d = ctx.empty((T, 3 * NCEPS), np.float32)
-    emis_d = ctx.empty((T, G), np.float32)
-    # emission matrix layout: state-major [G][T] (default) or frame-major [T][G]
-    ST_T, ST_G = (G, 1) if args.frame_major else (1, T)
+    # emission matrix layout: state-major [G][Tp] (default; rows 16-byte aligned: the alignment kernel then fetches four
+    # frames per load) or frame-major [T][G]
+    Tp = (T + 3) // 4 * 4
+    emis_d = ctx.empty((G, Tp), np.float32)
+    ST_T, ST_G = (G, 1) if args.frame_major else (1, Tp)
     path_d = ctx.zeros((T,), np.int32)
     final_d = ctx.zeros((n_utt,), np.float32)
     status_d = ctx.zeros((n_utt,), np.int32)

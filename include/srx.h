@@ -207,7 +207,9 @@ typedef struct {
  * Score is bit-exact w.r.t. the reference's f32 add order (it accumulates logp across a source's
  * transitions, src/hmm.cpp:164-169); exact ties are resolved towards the higher source index
  * (the reference's order is unordered_map iteration order, i.e. unspecified).
- * beam_width >= 1e10 (the reference default, src/hmm.cpp:150) disables the beam test. */
+ * beam_width >= 1e10 (the reference default, src/hmm.cpp:150) disables the beam test.
+ * Fastest layout: state-major with 16-byte aligned rows (stride_t == 1, stride_g a multiple of 4, emis_dev 16-byte
+ * aligned): four frames per load. */
 int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
                           int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
 

@@ -23,44 +23,74 @@ __device__ __forceinline__ float smooth_at(const float *__restrict__ raw, int64_
     return s / (float)NF;
 }
 
-__device__ __forceinline__ float delta_at(const float *__restrict__ raw, int64_t base, int64_t n, int64_t i, int q, int nc,
-                                          int WL) {
-    int64_t j = i - 1, k = i + 1;
-    if (j < 0) j = 0;
-    if (k == n) k--;
-    float a = smooth_at(raw, base, n, k, q, nc, WL);
-    float b = smooth_at(raw, base, n, j, q, nc, WL);
-    float d = a - b;
-    return d / (float)(k - j);
-}
+// One workgroup = FBK consecutive frames of the batch (they may span utterances).  Three stages through LDS, each value
+// computed once: smoothed cepstra for frames F0-2 .. F0+FBK+1, deltas for F0-1 .. F0+FBK, delta-deltas for F0 .. F0+FBK-1.
+// A frame's neighbours are clamped to its own utterance (src/mfcc.cpp:79-80,91-92), so every value a frame needs lies
+// within two frames of it.  Same operations in the same order as the scalar form (smooth_at; (a - b) / (k - j)).
+static constexpr int FBK = 64;
 
 __global__ __launch_bounds__(256) void k_features(const float *__restrict__ raw, const int64_t *__restrict__ foff, int n_utt,
                                                   int64_t total_frames, int nc, int WL, float *__restrict__ feats) {
-    const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= total_frames * nc) return;
-    const int64_t f = gi / nc;
-    const int q = (int)(gi - f * nc);
-    int lo = 0, hi = n_utt;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (foff[mid] <= f) lo = mid; else hi = mid;
+    extern __shared__ float fsh[];
+    float *sm = fsh;                               // [FBK + 4][nc]   frame F0 - 2 + r
+    float *dl = fsh + (FBK + 4) * nc;              // [FBK + 2][nc]   frame F0 - 1 + r
+    int64_t *ub = reinterpret_cast<int64_t *>(dl + (FBK + 2) * nc);   // [FBK + 4] utterance base of frame F0 - 2 + r
+    int64_t *un = ub + (FBK + 4);                                      // [FBK + 4] its length (0: no such frame)
+    const int64_t F0 = (int64_t)blockIdx.x * FBK;
+    for (int r = threadIdx.x; r < FBK + 4; r += 256) {
+        const int64_t f = F0 - 2 + r;
+        int64_t base = 0, n = 0;
+        if (f >= 0 && f < total_frames) {
+            int lo = 0, hi = n_utt;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (foff[mid] <= f) lo = mid; else hi = mid;
+            }
+            base = foff[lo];
+            n = foff[lo + 1] - base;
+        }
+        ub[r] = base;
+        un[r] = n;
     }
-    const int64_t base = foff[lo];
-    const int64_t n = foff[lo + 1] - base;
-    const int64_t i = f - base;
-    float c = smooth_at(raw, base, n, i, q, nc, WL);
-    float d = delta_at(raw, base, n, i, q, nc, WL);
-    int64_t j = i - 1, k = i + 1;
-    if (j < 0) j = 0;
-    if (k == n) k--;
-    float dk = delta_at(raw, base, n, k, q, nc, WL);
-    float dj = delta_at(raw, base, n, j, q, nc, WL);
-    float dd = dk - dj;
-    dd = dd / (float)(k - j);
-    float *o = feats + f * (3 * nc);
-    o[q] = c;
-    o[nc + q] = d;
-    o[2 * nc + q] = dd;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (FBK + 4) * nc; i += 256) {
+        const int r = i / nc, q = i - r * nc;
+        if (un[r] > 0) sm[i] = smooth_at(raw, ub[r], un[r], F0 - 2 + r - ub[r], q, nc, WL);
+    }
+    __syncthreads();
+    // row of frame (base + idx) in sm: its frame number minus (F0 - 2)
+    for (int i = threadIdx.x; i < (FBK + 2) * nc; i += 256) {
+        const int r = i / nc, q = i - r * nc;       // frame F0 - 1 + r  = sm row r + 1
+        const int64_t n = un[r + 1];
+        if (n > 0) {
+            const int64_t base = ub[r + 1], ii = F0 - 1 + r - base;
+            int64_t j = ii - 1, k = ii + 1;
+            if (j < 0) j = 0;
+            if (k == n) k--;
+            const float a = sm[(int)(base + k - (F0 - 2)) * nc + q];
+            const float b = sm[(int)(base + j - (F0 - 2)) * nc + q];
+            const float d = a - b;
+            dl[i] = d / (float)(k - j);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FBK * nc; i += 256) {
+        const int r = i / nc, q = i - r * nc;       // frame F0 + r = sm row r + 2 = dl row r + 1
+        const int64_t f = F0 + r;
+        if (f >= total_frames) continue;
+        const int64_t n = un[r + 2], base = ub[r + 2], ii = f - base;
+        int64_t j = ii - 1, k = ii + 1;
+        if (j < 0) j = 0;
+        if (k == n) k--;
+        const float dk = dl[(int)(base + k - (F0 - 1)) * nc + q];
+        const float dj = dl[(int)(base + j - (F0 - 1)) * nc + q];
+        float dd = dk - dj;
+        dd = dd / (float)(k - j);
+        float *o = feats + f * (3 * nc);
+        o[q] = sm[(r + 2) * nc + q];
+        o[nc + q] = dl[(r + 1) * nc + q];
+        o[2 * nc + q] = dd;
+    }
 }
 
 extern "C" int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const float *ceps_dev, const int64_t *frame_off_dev,
@@ -69,12 +99,13 @@ extern "C" int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const fl
     SRX_REQUIRE(ctx, ceps_dev && frame_off_dev && feats_dev, "srx_features_batch_dev: null argument");
     SRX_REQUIRE(ctx, WL >= 0 && WL <= 64 && n_ceps >= 1 && n_utt >= 0 && total_frames >= 0, "srx_features_batch_dev: bad size");
     if (n_utt == 0 || total_frames == 0) return SRX_OK;
-    const int64_t nthr = total_frames * n_ceps;
-    const int64_t nblk = ceil_div64(nthr, 256);
+    SRX_REQUIRE(ctx, n_ceps <= 64, "srx_features_batch_dev: n_ceps %d > 64", n_ceps);
+    const int64_t nblk = ceil_div64(total_frames, FBK);
     SRX_REQUIRE(ctx, nblk < (1ll << 31), "srx_features_batch_dev: too many frames");
+    const size_t lds = ((size_t)(FBK + 4) + (FBK + 2)) * n_ceps * sizeof(float) + 2 * (FBK + 4) * sizeof(int64_t);
     {
         SrxProf prof_(ctx, "k_features");
-        hipLaunchKernelGGL(k_features, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ceps_dev, frame_off_dev, n_utt, total_frames,
+        hipLaunchKernelGGL(k_features, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, ceps_dev, frame_off_dev, n_utt, total_frames,
                            n_ceps, WL, feats_dev);
     }
     SRX_LAUNCH_CHECK(ctx);

@@ -36,7 +36,10 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static constexpr int NEVER = 0x7fffffff;
 
-template <int SPL, bool BEAM>
+// VEC: state-major dense emissions with 16-byte aligned rows (stride_t == 1, stride_g % 4 == 0): a lane fetches four
+// consecutive frames of its state's row per load -- a quarter of the load instructions and of the cache-line lookups
+// (64 lanes read 64 different rows).  The frame loop then starts at the aligned frame at or before the utterance's first.
+template <int SPL, bool BEAM, bool VEC>
 __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                                 const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
                                                 const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
@@ -112,11 +115,26 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
 #pragma unroll
     for (int q = 0; q < SPL; q++) eoff[q] = (int64_t)col[q] * st_g;
     float er[PF][SPL];
+    const int a = VEC ? (int)(f0 & 3) : 0;                 // frames between the aligned start and the utterance's first
+    const int tlast4 = VEC ? (int)(((f0 + T - 1) & ~(int64_t)3) - f0) : 0;   // aligned group holding the last frame
+    if (VEC) {
 #pragma unroll
-    for (int p = 0; p < PF; p++) {
-        const int tt = p < T ? p : (T > 0 ? T - 1 : 0);
+        for (int p = 0; p < PF; p += 4) {
+            int tt = -a + p;
+            if (tt > tlast4) tt = tlast4;
 #pragma unroll
-        for (int q = 0; q < SPL; q++) er[p][q] = T > 0 ? erow[(int64_t)tt * st_t + eoff[q]] : 0.0f;
+            for (int q = 0; q < SPL; q++) {
+                const float4 v = T > 0 ? *reinterpret_cast<const float4 *>(erow + tt + eoff[q]) : make_float4(0, 0, 0, 0);
+                er[p][q] = v.x; er[p + 1][q] = v.y; er[p + 2][q] = v.z; er[p + 3][q] = v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            const int tt = p < T ? p : (T > 0 ? T - 1 : 0);
+#pragma unroll
+            for (int q = 0; q < SPL; q++) er[p][q] = T > 0 ? erow[(int64_t)tt * st_t + eoff[q]] : 0.0f;
+        }
     }
 
     uint32_t bw[SPL];
@@ -124,21 +142,31 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     for (int q = 0; q < SPL; q++) bw[q] = 0;
     float cur_best = -1e10f;
 
-    for (int tb = 0; tb < T; tb += PF) {
+    for (int tb = -a; tb < T; tb += PF) {
 #pragma unroll
         for (int p = 0; p < PF; p++) {
             const int t = tb + p;
-            if (t < T) {
-                float e[SPL];
+            float e[SPL];
 #pragma unroll
-                for (int q = 0; q < SPL; q++) e[q] = er[p][q];
-                // prefetch frame t + PF into the slot just consumed
-                {
-                    int tn = t + PF;
-                    if (tn >= T) tn = T - 1;
+            for (int q = 0; q < SPL; q++) e[q] = er[p][q];
+            // prefetch into the slot(s) just consumed: frame t + PF, or with VEC the four frames t - 3 + PF ..
+            if (VEC) {
+                if (p % 4 == 3) {
+                    int tn = t - 3 + PF;
+                    if (tn > tlast4) tn = tlast4;
 #pragma unroll
-                    for (int q = 0; q < SPL; q++) er[p][q] = erow[(int64_t)tn * st_t + eoff[q]];
+                    for (int q = 0; q < SPL; q++) {
+                        const float4 v = *reinterpret_cast<const float4 *>(erow + tn + eoff[q]);
+                        er[p - 3][q] = v.x; er[p - 2][q] = v.y; er[p - 1][q] = v.z; er[p][q] = v.w;
+                    }
                 }
+            } else if (t < T) {
+                int tn = t + PF;
+                if (tn >= T) tn = T - 1;
+#pragma unroll
+                for (int q = 0; q < SPL; q++) er[p][q] = erow[(int64_t)tn * st_t + eoff[q]];
+            }
+            if (t >= 0 && t < T) {
                 bool ok[SPL];
                 float c0[SPL], c1[SPL], c2[SPL];
                 if (BEAM) {
@@ -327,8 +355,12 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     if (rc != SRX_OK) return rc;
     const bool beam = beam_width < 1e10f;
     dim3 grid(hmm->n_utt), block(64);
+    const bool vec = !ebase_dev && stride_t == 1 && stride_g % 4 == 0 && stride_g >= total_frames &&
+                     (reinterpret_cast<uintptr_t>(emis_dev) & 15) == 0;
 #define SRX_VIT(SPLV, BEAMV)                                                                                              \
-    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,            \
+    do { if (vec) SRX_VIT2(SPLV, BEAMV, true); else SRX_VIT2(SPLV, BEAMV, false); } while (0)
+#define SRX_VIT2(SPLV, BEAMV, VECV)                                                                                       \
+    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, VECV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
                        hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, ebase_dev, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
     {
@@ -338,6 +370,7 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
         else { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
     }
 #undef SRX_VIT
+#undef SRX_VIT2
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }

@@ -30,8 +30,12 @@ def _make_batch(rng, n_utt, G, t_lo, t_hi, max_states=None, words=None):
 def _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam=1e10, state_major=False):
     hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
     if state_major:   # [G, T] layout, the one srx_gmm_score_dev writes fastest
-        emis_d = ctx.array(np.ascontiguousarray(emis.T))
-        path_d, final_d, status_d = hb.viterbi(emis_d, 1, emis.shape[0], beam)
+        T = emis.shape[0]
+        Tp = (T + 3) // 4 * 4 if state_major == "aligned" else T     # 16-byte aligned rows: four frames per load
+        buf = np.full((emis.shape[1], Tp), np.nan, np.float32)
+        buf[:, :T] = emis.T
+        emis_d = ctx.array(buf)
+        path_d, final_d, status_d = hb.viterbi(emis_d, 1, Tp, beam)
     else:
         emis_d = ctx.array(emis)
         path_d, final_d, status_d = hb.viterbi(emis_d, emis.shape[1], 1, beam)
@@ -57,6 +61,7 @@ def test_viterbi_bit_exact(ctx, oracle, words, spl):
     emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 20).astype(np.float32)
     _check(ctx, oracle, ntrs, trs, tieds, fo, emis)
     _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major=True)
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major="aligned")     # four frames per load
 
 
 def test_viterbi_positive_scores_and_short_T(ctx, oracle):
@@ -74,6 +79,7 @@ def test_viterbi_positive_scores_and_short_T(ctx, oracle):
     tieds = [rng.integers(0, G, len(ph)).astype(np.int32) for _ in range(n)]
     _, _, _, path, status = _check(ctx, oracle, [ntr] * n, [tr] * n, tieds, fo, emis)
     assert status[0] == 1 and status[-1] == 0 and status.sum() >= 2
+    _check(ctx, oracle, [ntr] * n, [tr] * n, tieds, fo, emis, state_major="aligned")   # utterances starting at every alignment
 
 
 def test_viterbi_finite_beam(ctx, oracle):
@@ -83,6 +89,7 @@ def test_viterbi_finite_beam(ctx, oracle):
     emis = (rng.standard_normal((int(fo[-1]), G)) * 6 - 10).astype(np.float32)
     for beam in (1e9, 200.0, 60.0, 25.0):
         _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam)
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, 60.0, state_major="aligned")
 
 
 def test_train_transition_probabilities(ctx, oracle):
