@@ -30,7 +30,18 @@ __global__ __launch_bounds__(1024) void k_sumsq_scale(const float *__restrict__ 
     const int u = blockIdx.x;
     const int64_t b = soff[u], e = soff[u + 1];
     double acc = 0.0;
-    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+    // four independent loads in flight per thread (one block streams a whole utterance)
+    int64_t i = b + threadIdx.x;
+    const int64_t st = blockDim.x;
+    for (; i + 3 * st < e; i += 4 * st) {
+        const float s0 = x[i], s1 = x[i + st], s2 = x[i + 2 * st], s3 = x[i + 3 * st];
+        const float q0 = s0 * s0, q1 = s1 * s1, q2 = s2 * s2, q3 = s3 * s3;
+        acc += (double)q0;
+        acc += (double)q1;
+        acc += (double)q2;
+        acc += (double)q3;
+    }
+    for (; i < e; i += st) {
         float s = x[i];
         float sq = s * s;
         acc += (double)sq;

@@ -26,6 +26,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 128-bit load from a 4-byte aligned address
 
 static constexpr int NW = 8;                 // waves per workgroup
 static constexpr int FRAMES_WG = NW * 32;
@@ -60,7 +61,8 @@ int srx_mfcc16_build(srx_mfcc_plan *p, const std::vector<float> &win, const std:
                 for (int lane = 0; lane < 64; lane++)
                     for (int e = 0; e < 8; e++) {
                         const int b = 32 * t + lane % 32, n = 16 * s + 8 * (lane / 32) + e;
-                        const float v = (b < p->bin_max && n < p->half) ? tw[((size_t)n * 2 + part) * p->NB + b] : 0.0f;
+                        // the window is folded into the table: (x w) cos = x (w cos)
+                        const float v = (b < p->bin_max && n < p->half) ? (float)((double)win[n] * (double)tw[((size_t)n * 2 + part) * p->NB + b]) : 0.0f;
                         _Float16 hi, lo;
                         split16(v, &hi, &lo);
                         ck[(((size_t)s * 2 + part) * 2 + 0) * frag + lane * 8 + e] = hi;
@@ -189,37 +191,39 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mfcc_f16(Mfcc16Args a) {
             const int n0 = 16 * s + 8 * hh;
             const int64_t base = p0 + n0;
             if (valid && n0 < a.half) {
+                // nine consecutive samples x[base-1 .. base+7] as two 128-bit loads and one 32-bit load (4-byte alignment is
+                // enough for global_load_dwordx4); the first frame of an utterance has no x[-1]: it loads x[0 .. 8] and shifts
+                const bool at0 = base == 0;
+                const float *src = xu + (at0 ? 0 : base - 1);
+                const f4u A = *reinterpret_cast<const f4u *>(src);
+                const f4u B = *reinterpret_cast<const f4u *>(src + 4);
+                const float C = src[8];
+                float W[9] = {A[0], A[1], A[2], A[3], B[0], B[1], B[2], B[3], C};
+                float L[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    float v = at0 ? W[i ? i - 1 : 0] : W[i];
+                    if (a.scale) v *= sc;   // normalizeVolume first (src/main.cpp:82), then pre-emphasis
+                    L[i] = v;
+                }
                 if (a.preemph) {
                     // v(p) = x[q] - alpha * x[q-1], q = max(p, 1)  (src/clip.cpp:199-205: x[0] takes the new x[1])
-                    float L[9];
-#pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        const int64_t q = base - 1 + i;
-                        float v = xu[q < 0 ? 0 : q];
-                        if (a.scale) v *= sc;   // normalizeVolume first (src/main.cpp:82), then pre-emphasis
-                        L[i] = v;
-                    }
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const float m = a.alpha * L[e];
                         y[s][e] = L[e + 1] - m;
                     }
-                    if (base == 0) {
+                    if (at0) {
                         const float m = a.alpha * L[1];
                         y[s][0] = L[2] - m;
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        float v = xu[base + e];
-                        if (a.scale) v *= sc;
-                        y[s][e] = v;
-                    }
+                    for (int e = 0; e < 8; e++) y[s][e] = L[e + 1];
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    const float wv = a.win16[n0 + e];   // 0 beyond the half window
-                    y[s][e] = n0 + e < a.half ? y[s][e] * wv : 0.0f;
+                    if (n0 + e >= a.half) y[s][e] = 0.0f;   // (the window itself is part of the table)
                     ymax = fmaxf(ymax, fabsf(y[s][e]));
                 }
             } else {
