@@ -365,7 +365,6 @@ extern "C" int srx_mfcc_plan_set_path(srx_mfcc_plan *p, int path) {
 
 extern "C" void srx_mfcc_plan_destroy(srx_mfcc_plan *p) {
     if (!p) return;
-    (void)hipFree(p->win16);
     (void)hipFree(p->pk16);
     (void)hipFree(p->dct16);
     (void)hipFree(p->win);

@@ -6,7 +6,7 @@
 //   filterbank::operator()  src/mfcc.cpp:143-149,161-167 -> GEMM2  [filters x bins] . [bins x frames]
 //   log(T*,int)  src/utils.hpp:55-60 -> logf(x + 1)
 //   dct  src/mfcc.cpp:205-214 -> GEMM3  [ceps x filters] . [filters x frames]
-//   normalizeVolume / preemphasis / hamming_window fused into the frame load as in srx_mfcc.hip
+//   normalizeVolume / preemphasis fused into the frame load as in srx_mfcc.hip; hamming_window folded into the twiddles
 //
 // Frames are the MFMA columns throughout: a lane owns one frame (lane % 32) and, in every accumulator, 16 of the 32 rows
 // of a tile.  The accumulators of one product are therefore, converted to f16 pairs, exactly the B fragments of the next
@@ -96,14 +96,10 @@ int srx_mfcc16_build(srx_mfcc_plan *p, const std::vector<float> &win, const std:
                     dk[(fi + 0) * frag + lane * 8 + e] = hi;
                     dk[(fi + 1) * frag + lane * 8 + e] = lo;
                 }
-    std::vector<float> w16((size_t)KS * 16, 0.0f);
-    for (int n = 0; n < p->half; n++) w16[n] = win[n];
     hipError_t e;
     if ((e = hipMalloc(&p->pk16, pk.size() * 2)) != hipSuccess || (e = hipMalloc(&p->dct16, dk.size() * 2)) != hipSuccess ||
-        (e = hipMalloc((void **)&p->win16, w16.size() * 4)) != hipSuccess ||
         (e = hipMemcpy(p->pk16, pk.data(), pk.size() * 2, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->dct16, dk.data(), dk.size() * 2, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(p->win16, w16.data(), w16.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+        (e = hipMemcpy(p->dct16, dk.data(), dk.size() * 2, hipMemcpyHostToDevice)) != hipSuccess)
         return srx_fail(p->ctx, SRX_ERR_DEVICE, "srx_mfcc_plan_create: f16 table upload failed: %s", hipGetErrorString(e));
     p->ks16 = KS;
     p->nbt16 = NBT;
@@ -115,7 +111,6 @@ struct Mfcc16Args {
     const int64_t *soff;
     const int64_t *foff;
     const float *scale;  // per-utterance gain, may be null
-    const float *win16;
     const f16x8 *pk16;
     const f16x8 *dct16;
     float *ceps;
@@ -343,7 +338,7 @@ int srx_mfcc16_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samp
     const srx_mfcc_cfg &c = plan->cfg;
     Mfcc16Args a;
     a.x = samples_dev; a.soff = sample_off_dev; a.foff = frame_off_dev; a.scale = scale_dev;
-    a.win16 = plan->win16; a.pk16 = (const f16x8 *)plan->pk16; a.dct16 = (const f16x8 *)plan->dct16;
+    a.pk16 = (const f16x8 *)plan->pk16; a.dct16 = (const f16x8 *)plan->dct16;
     a.ceps = ceps_dev; a.total_frames = total_frames; a.n_utt = n_utt; a.hop = c.frame_shift; a.half = plan->half;
     a.n_ceps = c.n_ceps; a.nbt = plan->nbt16; a.preemph = c.preemphasis; a.alpha = c.alpha; a.rootn_inv = plan->rootn_inv;
     const int KS = plan->ks16;

@@ -20,7 +20,6 @@ struct srx_mfcc_plan {
     int path = SRX_MFCC_AUTO;
     int ks16 = 0;           // 16-sample k-steps per half window
     int nbt16 = 0;          // 32-bin tiles
-    float *win16 = nullptr;   // [16*ks16], zero beyond half
     void *pk16 = nullptr;     // [nbt16] chunks of MFMA fragments: twiddles then filterbank columns of the tile
     void *dct16 = nullptr;    // DCT fragments
 };
