@@ -96,3 +96,90 @@ __device__ __forceinline__ void static_for16(std::integer_sequence<int, Is...>, 
     (f(std::integral_constant<int, Is>{}), ...);
 }
 
+
+// The log-sum-exp epilogue of one row tile, cut into NMF slices so that slice i can be issued between MFMA i and MFMA i+1
+// of the next tile (shared by k_gmm_f16 and k_gmm_f16_align).  accp = the tile's accumulators: register r of a lane is
+// component r % MP of the lane's state r / MP (log2 domain).  Slices [0, N1): per-state maxima; [N1, N1+N2): differences,
+// exp2, sums; the last N3: log2, scale to natural log, and store(f, st, value) for frame tile f, lane-local state st.
+// pin(): an empty asm the value passes through.  The arithmetic of a slice is pure, so instruction selection would
+// otherwise place it wherever it likes (it clustered all 32 v_sub/v_exp between two MFMAs); with its inputs pinned at
+// the start of the slice and its results at the end, each slice stays between its two MFMAs.
+template <int MP, int KS>
+struct LseEpilogue16 {
+    static constexpr int NST = 16 / MP;
+    static constexpr int NMF = 3 * KS * FT_PER_WAVE;          // MFMAs per row tile = slices
+    static constexpr int NEL = 16 * FT_PER_WAVE;              // accumulator registers (elements) per row tile
+    static constexpr int N1 = NMF >= 12 ? 2 : 1;
+    static constexpr int N3 = NMF >= 12 ? 2 : 1;
+    static constexpr int N2 = NMF - N1 - N3;
+    float mx[FT_PER_WAVE][NST], sum[FT_PER_WAVE][NST];
+
+    static __device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+
+    template <int I, class Store>
+    __device__ __forceinline__ void slice(const f32x16 (&accp)[FT_PER_WAVE], Store &&store) {
+        if constexpr (I < N1) {
+            if constexpr (MP > 1) {
+                constexpr int f0 = I * FT_PER_WAVE / N1, f1 = (I + 1) * FT_PER_WAVE / N1;
+#pragma unroll
+                for (int f = f0; f < f1; f++) {
+#pragma unroll
+                    for (int st = 0; st < NST; st++) {
+                        // v_max3 directly: fmaxf() on MFMA results gets a canonicalising v_max in front of every operand
+                        float m_ = accp[f][st * MP];
+                        pin(m_);
+                        if constexpr (MP == 2) {
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + 1]));
+                        } else {
+#pragma unroll
+                            for (int q = 1; q + 1 < MP; q += 2)
+                                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + q]), "v"(accp[f][st * MP + q + 1]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + MP - 1]));
+                        }
+                        pin(m_);
+                        mx[f][st] = m_;
+                        sum[f][st] = 0.0f;
+                    }
+                }
+            }
+        } else if constexpr (I < N1 + N2) {
+            if constexpr (MP > 1) {
+                constexpr int e0 = (I - N1) * NEL / N2, e1 = (I - N1 + 1) * NEL / N2;
+                float d_[e1 - e0 + 1];
+                // all differences, then all exponentials, then the sums: no instruction waits on the one before it
+#pragma unroll
+                for (int e = e0; e < e1; e++) {
+                    float a_ = accp[e / 16][e % 16];
+                    pin(a_);
+                    d_[e - e0] = a_ - mx[e / 16][(e % 16) / MP];
+                }
+#pragma unroll
+                for (int e = e0; e < e1; e++) d_[e - e0] = __builtin_amdgcn_exp2f(d_[e - e0]);
+#pragma unroll
+                for (int e = e0; e < e1; e++) sum[e / 16][(e % 16) / MP] += d_[e - e0];
+#pragma unroll
+                for (int e = e0; e < e1; e++)
+                    if (e == e1 - 1 || (e + 1) / MP != e / MP) pin(sum[e / 16][(e % 16) / MP]);
+            }
+        } else {
+            constexpr int k = I - N1 - N2;
+            constexpr int f0 = k * FT_PER_WAVE / N3, f1 = (k + 1) * FT_PER_WAVE / N3;
+#pragma unroll
+            for (int f = f0; f < f1; f++) {
+#pragma unroll
+                for (int st = 0; st < NST; st++) {
+                    float v;
+                    if constexpr (MP == 1) {
+                        v = accp[f][st];
+                    } else {
+                        float s_ = sum[f][st];
+                        pin(s_);
+                        v = (mx[f][st] + __builtin_amdgcn_logf(s_)) * kLn2f;
+                    }
+                    pin(v);
+                    store(f, st, v);
+                }
+            }
+        }
+    }
+};

@@ -300,101 +300,32 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
     // out by hand -- slice i of the epilogue after MFMA i, order pinned with sched_barrier -- because the scheduler
     // otherwise clusters the MFMAs.
     constexpr int NMF = 3 * KS * FT_PER_WAVE;          // MFMAs per row tile
-    constexpr int NEL = 16 * FT_PER_WAVE;              // accumulator registers (elements) per row tile
-    constexpr int N1 = NMF >= 12 ? 2 : 1;              // slices for the per-state maxima
-    constexpr int N3 = NMF >= 12 ? 2 : 1;              // slices for log / scale / hand-over
-    constexpr int N2 = NMF - N1 - N3;                  // slices for exp2 + sum
     // two accumulator sets that swap roles from tile to tile (no register copies): one is written by the MFMAs of the
     // current tile while the epilogue consumes the other
     f32x16 accA[FT_PER_WAVE], accB[FT_PER_WAVE];
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int f = 0; f < FT_PER_WAVE; f++) accA[f] = accB[f] = z;
-    float mx[FT_PER_WAVE][NST], sum[FT_PER_WAVE][NST];
+    LseEpilogue16<MP, KS> epi;
     int pend_stores = 0;        // store instructions issued since the last DMA issue (wave-uniform)
 
-    // Slice `i` of the epilogue of the tile whose accumulators are in accp; `pr` = that tile's position in its output
-    // group; tile_p = its index (non-WIDE only; < 0: none).  i and pr are compile-time, so every range is a constant.
-    // pin(): an empty asm the value passes through.  The arithmetic of a slice is pure, so instruction selection would
-    // otherwise place it wherever it likes (it clustered all 32 v_sub/v_exp between two MFMAs); with its inputs pinned at
-    // the start of the slice and its results at the end, each slice stays between its two MFMAs.
-    auto pin = [](float &x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
+    // Slice `i` of the epilogue (LseEpilogue16) of the tile whose accumulators are in accp; `pr` = that tile's position in
+    // its output group; tile_p = its index (non-WIDE only; < 0: none).  i and pr are compile-time.
     auto epi_slice = [&](auto ic, auto prc, const f32x16 (&accp)[FT_PER_WAVE], int tile_p) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value, pr = decltype(prc)::value;
-        if constexpr (i < N1) {
-            if constexpr (MP > 1) {
-                constexpr int f0 = i * FT_PER_WAVE / N1, f1 = (i + 1) * FT_PER_WAVE / N1;
-#pragma unroll
-                for (int f = f0; f < f1; f++) {
-#pragma unroll
-                    for (int st = 0; st < NST; st++) {
-                        // v_max3 directly: fmaxf() on MFMA results gets a canonicalising v_max in front of every operand
-                        float m_ = accp[f][st * MP];
-                        pin(m_);
-                        if constexpr (MP == 2) {
-                            asm("v_max_f32 %0, %1, %2" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + 1]));
-                        } else {
-#pragma unroll
-                            for (int q = 1; q + 1 < MP; q += 2)
-                                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + q]), "v"(accp[f][st * MP + q + 1]));
-                            asm("v_max_f32 %0, %1, %2" : "=v"(m_) : "v"(m_), "v"(accp[f][st * MP + MP - 1]));
-                        }
-                        pin(m_);
-                        mx[f][st] = m_;
-                        sum[f][st] = 0.0f;
-                    }
-                }
+        epi.template slice<i>(accp, [&](int f, int st, float v) __attribute__((always_inline)) {
+            if (WIDE) {
+                // staging row = state within the group; the offset is an immediate of the ds_write
+                *reinterpret_cast<__attribute__((address_space(3))) float *>(lds3 + stage_wr + ((f * RG + pr * SPT + st) * 32) * 4) = v;
+            } else {
+                const int64_t fr = (ft0 + f) * 32 + j;
+                const int g = tile_p * SPT + h * NST + st;
+                // branch-free (a conditional store would split the basic block and undo the interleave):
+                // lanes with nothing to write store to a dump slot
+                float *dst = (tile_p >= 0 && fr < T && g < G) ? out + fr * st_t + (int64_t)g * st_g : dump + lane;
+                *dst = v;
             }
-        } else if constexpr (i < N1 + N2) {
-            if constexpr (MP > 1) {
-                constexpr int e0 = (i - N1) * NEL / N2, e1 = (i - N1 + 1) * NEL / N2;
-                float d_[e1 - e0 + 1];
-                // all differences, then all exponentials, then the sums: no instruction waits on the one before it
-#pragma unroll
-                for (int e = e0; e < e1; e++) {
-                    float a_ = accp[e / 16][e % 16];
-                    pin(a_);
-                    d_[e - e0] = a_ - mx[e / 16][(e % 16) / MP];
-                }
-#pragma unroll
-                for (int e = e0; e < e1; e++) d_[e - e0] = __builtin_amdgcn_exp2f(d_[e - e0]);
-#pragma unroll
-                for (int e = e0; e < e1; e++) sum[e / 16][(e % 16) / MP] += d_[e - e0];
-#pragma unroll
-                for (int e = e0; e < e1; e++)
-                    if (e == e1 - 1 || (e + 1) / MP != e / MP) pin(sum[e / 16][(e % 16) / MP]);
-            }
-        } else {
-            constexpr int k = i - N1 - N2;
-            constexpr int f0 = k * FT_PER_WAVE / N3, f1 = (k + 1) * FT_PER_WAVE / N3;
-#pragma unroll
-            for (int f = f0; f < f1; f++) {
-#pragma unroll
-                for (int st = 0; st < NST; st++) {
-                    float v;
-                    if constexpr (MP == 1) {
-                        v = accp[f][st];
-                    } else {
-                        float s_ = sum[f][st];
-                        pin(s_);
-                        v = (mx[f][st] + __builtin_amdgcn_logf(s_)) * kLn2f;
-                    }
-                    pin(v);
-                    if (WIDE) {
-                        // staging row = state within the group; the offset is an immediate of the ds_write
-                        *reinterpret_cast<__attribute__((address_space(3))) float *>(lds3 + stage_wr +
-                                                                                      ((f * RG + pr * SPT + st) * 32) * 4) = v;
-                    } else {
-                        const int64_t fr = (ft0 + f) * 32 + j;
-                        const int g = tile_p * SPT + h * NST + st;
-                        // branch-free (a conditional store would split the basic block and undo the interleave):
-                        // lanes with nothing to write store to a dump slot
-                        float *dst = (tile_p >= 0 && fr < T && g < G) ? out + fr * st_t + (int64_t)g * st_g : dump + lane;
-                        *dst = v;
-                    }
-                }
-            }
-        }
+        });
     };
 
     // WIDE: write the staged output group whose first state is gfirst: per instruction 8 states x 32 frames, a lane stores

@@ -237,78 +237,20 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     };
 
     constexpr int NMF = 3 * KS * FT_PER_WAVE;
-    constexpr int NEL = 16 * FT_PER_WAVE;
-    constexpr int N1 = NMF >= 12 ? 2 : 1;
-    constexpr int N3 = NMF >= 12 ? 2 : 1;
-    constexpr int N2 = NMF - N1 - N3;
     f32x16 accA[FT_PER_WAVE], accB[FT_PER_WAVE];
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int f = 0; f < FT_PER_WAVE; f++) accA[f] = accB[f] = z;
-    float mx[FT_PER_WAVE][NST], sum[FT_PER_WAVE][NST];
-
-    auto pin = [](float &x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); };
-    // slice i of the log-sum-exp epilogue of row tile `tp` (< 0: none), see k_gmm_f16
+    LseEpilogue16<MP, KS> epi;
+    // slice i of the log-sum-exp epilogue of row tile `tp` (< 0: none), see LseEpilogue16
     auto epi_slice = [&](auto ic, const f32x16 (&accp)[FT_PER_WAVE], int tp) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (i < N1) {
-            if constexpr (MP > 1) {
-                constexpr int fa = i * FT_PER_WAVE / N1, fb = (i + 1) * FT_PER_WAVE / N1;
-#pragma unroll
-                for (int f = fa; f < fb; f++) {
-#pragma unroll
-                    for (int st = 0; st < NST; st++) {
-                        float m_ = accp[f][st * MP];
-                        pin(m_);
-#pragma unroll
-                        for (int q = 1; q < MP; q++) m_ = fmaxf(m_, accp[f][st * MP + q]);
-                        pin(m_);
-                        mx[f][st] = m_;
-                        sum[f][st] = 0.0f;
-                    }
-                }
-            }
-        } else if constexpr (i < N1 + N2) {
-            if constexpr (MP > 1) {
-                constexpr int e0 = (i - N1) * NEL / N2, e1 = (i - N1 + 1) * NEL / N2;
-                float d_[e1 - e0 + 1];
-#pragma unroll
-                for (int e = e0; e < e1; e++) {
-                    float a_ = accp[e / 16][e % 16];
-                    pin(a_);
-                    d_[e - e0] = a_ - mx[e / 16][(e % 16) / MP];
-                }
-#pragma unroll
-                for (int e = e0; e < e1; e++) d_[e - e0] = __builtin_amdgcn_exp2f(d_[e - e0]);
-#pragma unroll
-                for (int e = e0; e < e1; e++) sum[e / 16][(e % 16) / MP] += d_[e - e0];
-#pragma unroll
-                for (int e = e0; e < e1; e++)
-                    if (e == e1 - 1 || (e + 1) / MP != e / MP) pin(sum[e / 16][(e % 16) / MP]);
-            }
-        } else {
-            constexpr int k = i - N1 - N2;
-            constexpr int fa = k * FT_PER_WAVE / N3, fb = (k + 1) * FT_PER_WAVE / N3;
-#pragma unroll
-            for (int f = fa; f < fb; f++) {
-#pragma unroll
-                for (int st = 0; st < NST; st++) {
-                    float v;
-                    if constexpr (MP == 1) {
-                        v = accp[f][st];
-                    } else {
-                        float s_ = sum[f][st];
-                        pin(s_);
-                        v = (mx[f][st] + __builtin_amdgcn_logf(s_)) * kLn2f;
-                    }
-                    pin(v);
-                    // staging row = frame, column = state within the slab (a tile before the first writes a column that
-                    // the first real tile overwrites)
-                    const int tq = tp < 0 ? 0 : tp % TPS;
-                    stage[(f * 32 + j) * LDR + tq * SPT + hh * NST + st] = v;
-                }
-            }
-        }
+        epi.template slice<i>(accp, [&](int f, int st, float v) __attribute__((always_inline)) {
+            // staging row = frame, column = state within the slab (a tile before the first writes a column that the
+            // first real tile overwrites)
+            const int tq = tp < 0 ? 0 : tp % TPS;
+            stage[(f * 32 + j) * LDR + tq * SPT + hh * NST + st] = v;
+        });
     };
     // writes slab `sb` (states sb*SB ..): 64 lanes walk the [64][SB] block row-major, so a row's SB states leave as one
     // contiguous segment of the frame-major output
