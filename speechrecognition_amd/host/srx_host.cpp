@@ -101,6 +101,17 @@ srx_ctx *context() {
     return g_ctx;
 }
 void set_verbose(bool on) { g_verbose = on; }
+// A generator of this layer's own: libc's rand() is shared with whatever else the process loads, and draws made
+// on the device runtime's threads made random initialisation differ from run to run.
+static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+void seed_random(unsigned seed) { g_rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed * 0xD1342543DE82EF95ull); }
+double next_random() {   // splitmix64 -> [0, 1)
+    uint64_t z = (g_rng += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
 bool verbose() { return g_verbose; }
 }  // namespace srx
 
@@ -541,7 +552,7 @@ gaussian::gaussian() : weight(1), logwt(0), zetasum(0) {
         var[i] = 1;
     }
 }
-static float uniform_rand(float lo, float hi) { return lo + (hi - lo) * (float)(std::rand() / (RAND_MAX + 1.0)); }
+static float uniform_rand(float lo, float hi) { return lo + (hi - lo) * (float)srx::next_random(); }
 void gaussian::initialize(featurevec &mu, featurevec &sigma2) {
     for (int i = 0; i < FV_LEN; i++) {
         float sd = std::sqrt(sigma2[i]);

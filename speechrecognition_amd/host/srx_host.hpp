@@ -9,12 +9,12 @@
 //   clip.hpp   ClipBuffer, ClipArrayBuffer, Clip (view, slide, rmsAmplitude, normalizeVolume, preemphasis, *=)
 //   wav.hpp    read_wav, write_wav, wav_io_exception
 //   utils.hpp  readlines, hamming_window
-//   pronounce.hpp  phone::phone, phone::context, phone::ties, phspec, findPhone   (no lexicon / pronouncer)
+//   pronounce.hpp  phone::phone, phone::context, phone::ties, phspec, findPhone, pronlist, pronlex, pronouncer
 //   gmm.hpp    gaussian, gmm, acoustic_model
 //   hmm.hpp    hmm_state, state_model, hmm (training-HMM constructor, viterbi, train_transition_probabilities,
 //              train, update_states)
 //   utterance.hpp  utterance, mean, variance
-// Not mirrored (outside the hot path): ofApp, cluster, langmodel, pronlex/pronouncer, the
+// Not mirrored (outside the hot path): ofApp, cluster, langmodel, the
 // lexicon-HMM constructor, the microphone ClipBuffer constructors, filter::operator() / filterbank::operator()
 // / dct / Clip::partial_dft as stand-alone per-frame host calls (they exist only fused inside the MFCC kernel).
 //
@@ -66,6 +66,8 @@ namespace srx {
 srx_ctx *context();            // the process-wide context (device SRX_DEVICE or 0), created on first use
 void set_verbose(bool on);     // the reference prints constantly (e.g. src/mfcc.cpp:279, src/hmm.cpp:217); default off
 bool verbose();
+void seed_random(unsigned seed);   // generator behind gaussian::initialize (the reference draws from ofRandom there)
+double next_random();              // uniform in [0, 1)
 }  // namespace srx
 
 // ------------------------------------------------------------------------------------------ utils.hpp
@@ -196,6 +198,29 @@ extern const char *names[];
 typedef std::pair<phone::phone, phone::subphone> phspec;
 phone::phone findPhone(std::string s);                                                   // src/pronounce.cpp:16-26
 
+// Text front end of the training path (srx_text.cpp): host string work that picks each utterance's states.
+class pronlist {                                                                         // src/pronounce.hpp:84-91
+public:
+    std::vector<std::vector<phone::phone>> pronunciations;
+    pronlist();
+    void add(std::vector<phone::phone> pron);
+};
+class pronlex {                                                                          // src/pronounce.hpp:94-106
+public:
+    std::map<std::string, pronlist> pr;
+    pronlex();
+    pronlex(std::istream &in);                             // CMU Pronouncing Dictionary format, src/pronounce.cpp:105-138
+    void add(std::string w, std::vector<phone::phone> pron);
+    pronlist *get(std::string w);                          // NULL when absent, src/pronounce.cpp:141-147
+};
+class pronouncer {                                                                       // src/pronounce.hpp:110-121
+public:
+    pronlex main, prefixes, suffixes;
+    pronouncer(const char *main_fn, const char *pre_fn, const char *suf_fn);
+    std::vector<phone::phone> pronounce_word(std::string w);   // throws 1 when it gives up, src/pronounce.cpp:178-257
+    std::vector<phone::phone> pronounce(std::string s);        // src/pronounce.cpp:260-278
+};
+
 // ------------------------------------------------------------------------------------------ gmm.hpp
 typedef long double prob_t;
 typedef float logprob_t;
@@ -207,7 +232,7 @@ public:
     prob_t var[FV_LEN];
     prob_t zetasum;
     gaussian();
-    void initialize(featurevec &mu, featurevec &sigma2);   // src/gmm.cpp:26-33 (rand() stands in for ofRandom)
+    void initialize(featurevec &mu, featurevec &sigma2);   // src/gmm.cpp:26-33 (srx::seed_random stands in for ofRandom's generator)
     void set_wt(float wt);                                 // src/gmm.cpp:35-38
 };
 
@@ -308,8 +333,9 @@ public:
     std::vector<phone::phone> pronunciation;
     class hmm *hmm;
     std::vector<featurevec *> features;
-    // The reference constructor takes a pronouncer (text -> phones, host text processing, out of scope);
-    // here the PROMPTS-style line carries the phone names instead: "<mfc path> PH PH PH ...".
+    // One line of a Voxforge PROMPTS file, "<mfc path> WORD WORD ...", pronounced by `pr` (src/utterance.cpp:14-28).
+    utterance(std::istream &in, std::string path_base, acoustic_model &acm, pronouncer &pr);
+    // [batch] the same line with the phone names already spelled out: "<mfc path> PH PH PH ...".
     utterance(std::istream &in, std::string path_base, acoustic_model &acm);
     utterance(const std::string &text, const std::vector<phone::phone> &pron, const std::vector<featurevec *> &fv,
               acoustic_model &acm);

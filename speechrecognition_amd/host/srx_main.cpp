@@ -5,11 +5,15 @@
 //   srx --mode mfcc  --voxforge DIR/ [--list _list]  [--window 320 --shift 160] [--batch 256] [--verbose]
 //   srx --mode train --voxforge DIR/ [--list _train] [--iters 80] [--mix 1] [--seed 1] [--out model.txt]
 //   srx --mode align --voxforge DIR/ [--list _train] [--model model.txt] [--out paths.txt]
+//   srx --mode pronounce --lexicon cmu.txt [--prefixes prefixes.txt --suffixes suffixes.txt]   (text lines on stdin)
+//
+// train/align take the same --lexicon/--prefixes/--suffixes: with a lexicon the transcripts are read from
+// <folder>etc/PROMPTS ("<mfc path relative to DIR> WORD WORD ...") and pronounced as the reference does
+// (src/main.cpp:27, 43); without one, from <folder>etc/PHONES ("<mfc path relative to DIR> PH PH ...").
 //
 // Corpus layout (README:26-39 of the reference): DIR/<list file> names one submission folder per line;
 // <folder>etc/PROMPTS has one "<path>/<wavname> words..." line per recording; audio in <folder>wav/<wavname>.wav,
-// features go to <folder>mfc/<wavname>.  Training reads <folder>etc/PHONES ("<mfc path relative to DIR> PH PH ...")
-// because the text front end (pronouncer, src/pronounce.cpp) is outside this build.
+// features go to <folder>mfc/<wavname>.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,14 +88,14 @@ static int run_mfcc(const string &dir, const string &list, unsigned wl, unsigned
     return 0;
 }
 
-static void load_corpus(const string &dir, const string &list, acoustic_model &acm, vector<utterance> &ut) {
+static void load_corpus(const string &dir, const string &list, acoustic_model &acm, vector<utterance> &ut, pronouncer *pron) {
     vector<string> folders = readlines(dir + list);
     for (size_t i = 0; i < folders.size(); i++) {
         if (folders[i].empty()) continue;
-        ifstream prompts((dir + folders[i] + "etc/PHONES").c_str());
+        ifstream prompts((dir + folders[i] + (pron ? "etc/PROMPTS" : "etc/PHONES")).c_str());
         while (prompts.good() && prompts.peek() != EOF) {
             try {
-                ut.push_back(utterance(prompts, dir, acm));
+                ut.push_back(pron ? utterance(prompts, dir, acm, *pron) : utterance(prompts, dir, acm));
             } catch (int ex) {
                 cout << "Caught exception " << ex << endl;  // src/main.cpp:44-48
             }
@@ -123,18 +127,23 @@ static bool load_model(acoustic_model &acm, const string &fname) {
     string tag;
     int G, M, D;
     if (!(in >> tag >> G >> M >> D) || tag != "srx-model" || G != acm.num_states() || M != acm.num_mix() || D != FV_LEN) return false;
+    // numbers go through strtod: a state that saw no frames holds nan (0/0, as in the reference), which
+    // operator>> does not read back
+    auto num = [&in]() {
+        string t;
+        in >> t;
+        return strtod(t.c_str(), nullptr);
+    };
     for (acm_iter it = acm.begin(); it != acm.end(); it++) {
         int p, c, n;
         in >> tag >> p >> c >> n;
         for (gaussian &g : it->second->gaussians) {
-            double v;
-            float w;
-            in >> tag >> w;
-            g.set_wt(w);
             in >> tag;
-            for (int i = 0; i < FV_LEN; i++) { in >> v; g.mean[i] = v; }
+            g.set_wt((float)num());
             in >> tag;
-            for (int i = 0; i < FV_LEN; i++) { in >> v; g.var[i] = v; }
+            for (int i = 0; i < FV_LEN; i++) g.mean[i] = num();
+            in >> tag;
+            for (int i = 0; i < FV_LEN; i++) g.var[i] = num();
         }
     }
     acm.mark_host_dirty();
@@ -145,22 +154,41 @@ int main(int argc, char **argv) {
     const string mode = arg(argc, argv, "--mode", "");
     string dir = arg(argc, argv, "--voxforge", "");
     srx::set_verbose(flag(argc, argv, "--verbose"));
-    if (mode.empty() || dir.empty()) {
-        cerr << "usage: srx --mode mfcc|train|align --voxforge DIR/ [options]  (see the head of srx_main.cpp)" << endl;
+    const string lexicon = arg(argc, argv, "--lexicon", "");
+    if (mode.empty() || (dir.empty() && mode != "pronounce") || (mode == "pronounce" && lexicon.empty())) {
+        cerr << "usage: srx --mode mfcc|train|align --voxforge DIR/ [options] | --mode pronounce --lexicon FILE"
+                "  (see the head of srx_main.cpp)" << endl;
         return 2;
     }
-    if (dir[dir.size() - 1] != '/') dir += '/';
+    if (!dir.empty() && dir[dir.size() - 1] != '/') dir += '/';
     try {
+        pronouncer *pron = nullptr;
+        if (!lexicon.empty())   // src/main.cpp:27; a missing affix file reads as an empty lexicon
+            pron = new pronouncer(lexicon.c_str(), arg(argc, argv, "--prefixes", "/dev/null").c_str(),
+                                  arg(argc, argv, "--suffixes", "/dev/null").c_str());
+        if (mode == "pronounce") {
+            string line;
+            while (getline(cin, line)) {
+                try {
+                    vector<phone::phone> ph = pron->pronounce(line);
+                    for (size_t i = 0; i < ph.size(); i++) cout << (i ? " " : "") << phone::names[ph[i]];
+                    cout << endl;
+                } catch (int ex) {
+                    cout << "!" << ex << endl;
+                }
+            }
+            return 0;
+        }
         if (mode == "mfcc")
             return run_mfcc(dir, arg(argc, argv, "--list", "_list"), (unsigned)atoi(arg(argc, argv, "--window", "320").c_str()),
                             (unsigned)atoi(arg(argc, argv, "--shift", "160").c_str()), atoi(arg(argc, argv, "--batch", "256").c_str()));
         if (mode == "train" || mode == "align") {
-            srand((unsigned)atoi(arg(argc, argv, "--seed", "1").c_str()));
+            srx::seed_random((unsigned)atoi(arg(argc, argv, "--seed", "1").c_str()));
             phone::ties acm_ties(phone::ties::NULL_CONTEXT);   // src/main.cpp:34-36
             phone::ties hmm_ties(phone::ties::PHONE_CLASSES);
             acoustic_model acm(acm_ties, atoi(arg(argc, argv, "--mix", "1").c_str()));
             vector<utterance> ut;
-            load_corpus(dir, arg(argc, argv, "--list", "_train"), acm, ut);
+            load_corpus(dir, arg(argc, argv, "--list", "_train"), acm, ut, pron);
             if (ut.empty()) return 1;
             const string model_in = arg(argc, argv, "--model", "");
             if (!model_in.empty()) {

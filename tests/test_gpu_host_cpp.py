@@ -231,3 +231,49 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
         r = oracle.viterbi(e, gidx[u], ntr, tr)
         assert [int(v) for v in row[2:]] == list(r["path"]), u
         assert abs(float(row[1]) - r["prevp"]) <= 1e-6 * abs(r["prevp"])
+
+
+def test_headless_driver_prompts_through_the_lexicon(tmp_path):
+    """--lexicon: transcripts from etc/PROMPTS pronounced by the host layer's pronouncer (src/main.cpp:27, 43;
+    src/utterance.cpp:14-28) give the alignment that the same phone strings give through etc/PHONES; an
+    unpronounceable line drops its utterance (src/main.cpp:44-48)."""
+    from oracle import pronounce as P
+    lex = [os.path.join(ROOT, "tests", "golden", "lexicon", n + ".txt") for n in ("main", "prefixes", "suffixes")]
+    pr = P.load(*lex)
+    rng = np.random.default_rng(5)
+    root = str(tmp_path / "vox") + "/"
+    os.makedirs(root)
+    folders, samples = _make_corpus(root, rng)
+    _run([SRX, "--mode", "mfcc", "--voxforge", root])
+    texts = ["THE QUICK DOG", "WALKING DOGS", "UNHAPPY CAT", "HOUSEBOAT", "MOTHER-IN-LAW", "BEWALKED A CAT"]
+    k = 0
+    for fo in folders:
+        prompts, phones = [], []
+        for (f2, name) in sorted(samples):
+            if f2 != fo:
+                continue
+            prompts.append("%smfc/%s %s" % (fo, name, texts[k]))
+            try:
+                phones.append("%smfc/%s %s" % (fo, name, " ".join(PHONE_NAMES[i] for i in pr.pronounce(texts[k]))))
+            except P.Unpronounceable:
+                pass
+            k += 1
+        open(os.path.join(root, fo, "etc", "PROMPTS"), "w").write("\n".join(prompts) + "\n")
+        open(os.path.join(root, fo, "etc", "PHONES"), "w").write("\n".join(phones) + "\n")
+    env = {"SRX_SCORE_PATH": "exact"}
+    _run([SRX, "--mode", "train", "--voxforge", root, "--iters", "2", "--seed", "4", "--out", root + "m.txt"], env)
+    a = _run([SRX, "--mode", "align", "--voxforge", root, "--model", root + "m.txt"], env)
+    b = _run([SRX, "--mode", "align", "--voxforge", root, "--model", root + "m.txt", "--lexicon", lex[0], "--prefixes", lex[1],
+              "--suffixes", lex[2]], env)
+    rows_a = [ln for ln in a.splitlines() if ln and ln[0].isdigit()]
+    rows_b = [ln for ln in b.splitlines() if ln and ln[0].isdigit()]
+    assert len(rows_a) == 5 and rows_a == rows_b
+    assert "Caught exception 1" in b and "Got 5 utterances" in b
+    # and training from the text gives the model that training from the phone strings gives
+    _run([SRX, "--mode", "train", "--voxforge", root, "--iters", "2", "--seed", "4", "--out", root + "m2.txt", "--lexicon", lex[0],
+          "--prefixes", lex[1], "--suffixes", lex[2]], env)
+    def nums(fn):
+        return np.array([float(v) for ln in open(fn) if ln[:4] in ("mean", "var ") for v in ln.split()[1:]])
+    m1, m2 = nums(root + "m.txt"), nums(root + "m2.txt")
+    assert m1.size == 40 * 26 and np.isfinite(m1).sum() >= 26 * 10
+    np.testing.assert_allclose(m2, m1, rtol=1e-9, equal_nan=True)   # summation order inside the device sums is not fixed
