@@ -130,11 +130,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # SRX_BENCH_BACKEND=gloo is the rehearsal of the N>1 control flow on a box with fewer GPUs than ranks (ranks then
+    # share devices and the two scalar reductions go through host memory); the driver's runs use nccl (= RCCL).
+    backend = os.environ.get("SRX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(local)
@@ -217,7 +225,7 @@ def main():
     status = status_d.get()
     assert (status == 0).all(), "alignment failed for some utterance"
 
-    tot = torch.tensor([dt, float(T)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([dt, float(T)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
