@@ -21,7 +21,16 @@
 // an SGPR.
 #include "srx_common.h"
 
-static constexpr int PF = 8;  // emission prefetch depth (frames)
+#include <type_traits>
+
+// Emission prefetch depth in frames.  The frame loop is a dependent chain of about 0.06 us per step and an emission
+// load takes 1-2 us to come back (64 lanes, 64 different rows), so the loads in flight have to cover 20-30 steps.
+#ifndef SRX_VIT_PF_VEC
+#define SRX_VIT_PF_VEC 32
+#endif
+#ifndef SRX_VIT_PF
+#define SRX_VIT_PF 16
+#endif
 
 __device__ __forceinline__ float shr1(float v) {
     // lane i receives lane i-1's value; lane 0 receives 0 (never used: its thresholds are never met)
@@ -39,7 +48,7 @@ static constexpr int NEVER = 0x7fffffff;
 // VEC: state-major dense emissions with 16-byte aligned rows (stride_t == 1, stride_g % 4 == 0): a lane fetches four
 // consecutive frames of its state's row per load -- a quarter of the load instructions and of the cache-line lookups
 // (64 lanes read 64 different rows).  The frame loop then starts at the aligned frame at or before the utterance's first.
-template <int SPL, bool BEAM, bool VEC>
+template <int SPL, bool BEAM, bool VEC, int PF>
 __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                                 const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
                                                 const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
@@ -55,21 +64,36 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     constexpr int SL = 64 * SPL;
     uint32_t *bpw_base = bpws + ((size_t)(f0 >> 4) + (size_t)u) * SL;
 
-    // minimum number of steps from state 0 (static reachability of the left-to-right topology)
+    // minimum number of steps from state 0 (static reachability of the left-to-right topology).  The recurrence is
+    // serial in s, so it must not wait on memory: the transition counts come into LDS with one coalesced load first,
+    // and the two running values stay in registers (the loop's only dependent chain is integer arithmetic).
     __shared__ int dmin[SL + 2];
+    __shared__ int s_ntr[SL];
+#pragma unroll
+    for (int q = 0; q < SPL; q++) {
+        const int s = q * 64 + lane;
+        s_ntr[s] = s < S ? ntr[s0 + s] : 0;
+    }
+    __syncthreads();
     if (lane == 0) {
         dmin[0] = NEVER;  // s = -2
         dmin[1] = NEVER;  // s = -1
+        int d1 = NEVER, d2 = NEVER;   // dmin of states s-1 and s-2
         for (int s = 0; s < S; s++) {
             int d = s == 0 ? 0 : NEVER;
-            if (s >= 1 && dmin[s + 1] != NEVER) d = dmin[s + 1] + 1;
-            if (s >= 2 && ntr[s0 + s - 2] == 3 && dmin[s] != NEVER && dmin[s] + 1 < d) d = dmin[s] + 1;
+            if (s >= 1 && d1 != NEVER) d = d1 + 1;
+            if (s >= 2 && s_ntr[s - 2] == 3 && d2 != NEVER && d2 + 1 < d) d = d2 + 1;
             dmin[s + 2] = d;
+            d2 = d1;
+            d1 = d;
         }
         for (int s = S; s < SL; s++) dmin[s + 2] = NEVER;
     }
     __syncthreads();
 
+#ifdef SRX_VIT_TIMING
+    const long long tk0 = wall_clock64();
+#endif
     float dl[SPL], a0[SPL], a1[SPL], a2[SPL];
     int tv0[SPL], tv1[SPL], tv2[SPL], col[SPL];
     bool act[SPL];
@@ -85,11 +109,11 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
             col[q] = ebase ? s : tied[s0 + s];   // compact per-utterance block: the row is the state itself
             a0[q] = trlogp[(size_t)(s0 + s) * 3];
             tv0[q] = dmin[s + 2];
-            if (s >= 1 && ntr[s0 + s - 1] >= 2) {
+            if (s >= 1 && s_ntr[s - 1] >= 2) {
                 a1[q] = trlogp[(size_t)(s0 + s - 1) * 3 + 1];
                 tv1[q] = dmin[s + 1];
             }
-            if (s >= 2 && ntr[s0 + s - 2] == 3) {
+            if (s >= 2 && s_ntr[s - 2] == 3) {
                 a2[q] = trlogp[(size_t)(s0 + s - 2) * 3 + 2];
                 tv2[q] = dmin[s];
             }
@@ -100,8 +124,8 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
 #pragma unroll
     for (int q = 0; q < SPL; q++) {
         const int s = lane * SPL + q;
-        has1[q] = (s < S && s >= 1) ? ntr[s0 + s - 1] >= 2 : false;
-        has2[q] = (s < S && s >= 2) ? ntr[s0 + s - 2] == 3 : false;
+        has1[q] = (s < S && s >= 1) ? s_ntr[s - 1] >= 2 : false;
+        has2[q] = (s < S && s >= 2) ? s_ntr[s - 2] == 3 : false;
     }
 
     // dense matrix: frame t of the batch, column tied[s]; compact (alignment-mode scoring): utterance block [T][S] at
@@ -142,7 +166,19 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     for (int q = 0; q < SPL; q++) bw[q] = 0;
     float cur_best = -1e10f;
 
-    for (int tb = -a; tb < T; tb += PF) {
+    // Back-pointer words are indexed from the aligned start: frame t sits in word (t + a) >> 4 at bit pair (t + a) & 15.
+    // Blocks start at multiples of PF from there and PF is a multiple of 16, so inside the unrolled block both the
+    // shift and the "word is full" test are compile-time.  A block whose PF frames all exist runs without per-step
+    // range tests (GUARD = false); the first block of an unaligned utterance and the last one take the guarded copy.
+    static_assert(PF % 16 == 0, "PF must cover whole back-pointer words");
+    // STATIC (alignment without a beam only): from frame t_static on every threshold test `t >= tv` has its final
+    // value -- each state below S can be continued (ok), and a candidate exists exactly where the transition does --
+    // so the step keeps two compares and four selects per state.  Lanes at or above S compute garbage that nothing
+    // reads (values only move towards higher lanes).
+    auto run_block = [&](auto mode_tag, const int tb) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;   // 0 guarded, 1 unguarded, 2 unguarded + static flags
+        constexpr bool GUARD = MODE == 0;
+        constexpr bool STATIC = MODE == 2;
 #pragma unroll
         for (int p = 0; p < PF; p++) {
             const int t = tb + p;
@@ -160,16 +196,17 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
                         er[p - 3][q] = v.x; er[p - 2][q] = v.y; er[p - 1][q] = v.z; er[p][q] = v.w;
                     }
                 }
-            } else if (t < T) {
+            } else if (!GUARD || t < T) {
                 int tn = t + PF;
                 if (tn >= T) tn = T - 1;
 #pragma unroll
                 for (int q = 0; q < SPL; q++) er[p][q] = erow[(int64_t)tn * st_t + eoff[q]];
             }
-            if (t >= 0 && t < T) {
+            if (!GUARD || (t >= 0 && t < T)) {
                 bool ok[SPL];
                 float c0[SPL], c1[SPL], c2[SPL];
-                if (BEAM) {
+                if (STATIC) {
+                } else if (BEAM) {
                     const float thresh = cur_best - beam;
 #pragma unroll
                     for (int q = 0; q < SPL; q++) ok[q] = act[q] && !(dl[q] < thresh);
@@ -195,6 +232,17 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
                     c2[q] = x + e[q];
                 }
                 bool v1[SPL], v2[SPL];
+                if (STATIC) {
+#pragma unroll
+                    for (int q = 0; q < SPL; q++) {
+                        const bool t1 = has1[q] && (c1[q] > c0[q]);
+                        const float b1 = t1 ? c1[q] : c0[q];
+                        const bool t2 = has2[q] && (c2[q] > b1);
+                        dl[q] = t2 ? c2[q] : b1;
+                        const uint32_t bp = t2 ? 2u : (t1 ? 1u : 0u);
+                        bw[q] |= bp << (2 * (p & 15));
+                    }
+                } else {
                 if (BEAM) {
                     int okl = ok[SPL - 1] ? 1 : 0;
                     int okl2 = SPL >= 2 ? (ok[SPL >= 2 ? SPL - 2 : 0] ? 1 : 0) : 0;
@@ -217,30 +265,68 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
                 float nb = -__builtin_huge_valf();
 #pragma unroll
                 for (int q = 0; q < SPL; q++) {
-                    bool have = ok[q];
-                    float best = c0[q];
-                    uint32_t bp = 0;
-                    if (v1[q] && (!have || c1[q] > best)) { best = c1[q]; bp = 1; have = true; }
-                    if (v2[q] && (!have || c2[q] > best)) { best = c2[q]; bp = 2; have = true; }
-                    if (have) dl[q] = best;
+                    // selects only, no control flow: a candidate replaces the running best if it exists and either
+                    // nothing was there yet or it is strictly greater (src/hmm.cpp:172-184)
+                    const bool t1 = v1[q] & (!ok[q] | (c1[q] > c0[q]));
+                    const float b1 = t1 ? c1[q] : c0[q];
+                    const bool h1 = ok[q] | v1[q];
+                    const bool t2 = v2[q] & (!h1 | (c2[q] > b1));
+                    const float b2 = t2 ? c2[q] : b1;
+                    const bool have = h1 | v2[q];
+                    dl[q] = have ? b2 : dl[q];
+                    const uint32_t bp = t2 ? 2u : (t1 ? 1u : 0u);
                     if (BEAM) {
                         act[q] = have;
-                        if (have) nb = fmaxf(nb, best);
+                        nb = have ? fmaxf(nb, b2) : nb;
                     }
-                    bw[q] |= bp << (2 * (t & 15));
+                    bw[q] |= bp << (2 * (p & 15));
                 }
                 if (BEAM) cur_best = fmaxf(-1e10f, wave_max(nb));
-                if ((t & 15) == 15 || t == T - 1) {
+                }
+                if ((p & 15) == 15 || (GUARD && t == T - 1)) {
 #pragma unroll
                     for (int q = 0; q < SPL; q++) {
-                        bpw_base[(size_t)(t >> 4) * SL + lane * SPL + q] = bw[q];
+                        bpw_base[(size_t)((t + a) >> 4) * SL + lane * SPL + q] = bw[q];
                         bw[q] = 0;
                     }
                 }
             }
         }
+    };
+#ifdef SRX_VIT_TIMING
+    const long long tk1 = wall_clock64();
+#endif
+#ifndef SRX_VIT_NOLOOP
+    // frame from which all threshold tests have settled (uniform over the wave)
+    int t_static = 0;
+    if (!BEAM) {
+#pragma unroll
+        for (int q = 0; q < SPL; q++) {
+            if (tv0[q] != NEVER && tv0[q] > t_static) t_static = tv0[q];
+            if (tv1[q] != NEVER && tv1[q] > t_static) t_static = tv1[q];
+            if (tv2[q] != NEVER && tv2[q] > t_static) t_static = tv2[q];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(t_static, o, 64);
+            t_static = other > t_static ? other : t_static;
+        }
+        t_static = __builtin_amdgcn_readfirstlane(t_static);
     }
+    for (int tb = -a; tb < T; tb += PF) {
+        const bool whole = tb >= 0 && tb + PF <= T;
+        if (BEAM) {
+            if (whole) run_block(std::integral_constant<int, 1>{}, tb);
+            else run_block(std::integral_constant<int, 0>{}, tb);
+        } else {
+            if (whole && tb >= t_static) run_block(std::integral_constant<int, 2>{}, tb);
+            else run_block(std::integral_constant<int, 0>{}, tb);
+        }
+    }
+#endif
 
+#ifdef SRX_VIT_TIMING
+    const long long tk2 = wall_clock64();
+#endif
     // ---- end condition: the path must end in the last state (src/hmm.cpp:210-215) ----
     const int last = S - 1;
     const int owner = last / SPL, oq = last % SPL;
@@ -274,28 +360,82 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     // ---- backtrace (src/hmm.cpp:219-222): current state b is wave-uniform ----
     int b = last;
     int pv = 0;
-    for (int kb = (T - 1) >> 4; kb >= 0; kb--) {
-        uint32_t w[SPL];
+#ifdef SRX_VIT_NOBT
+    if (T > 0) return;
+#endif
+    // The walk is one dependent chain per frame, so it must not wait on memory either: the back-pointer words come
+    // into LDS a chunk of BT_CH groups (16 frames each) at a time with all loads in flight together, and the walk
+    // reads the next group's registers from LDS while it steps through the current one.  Lane (t + a) & 63 of `pv`
+    // collects the state of frame t; 64 frames go out in one store.  A whole group is walked with compile-time shifts.
+    constexpr int BT_CH = 32;
+    __shared__ uint32_t s_bp[BT_CH * SL];
+    const int ng = ((T - 1 + a) >> 4) + 1;
+    // One step: the 2-bit field of frame j in the current state's word is the decrement; it is also OR-ed, in place,
+    // into `dec`, from which the lanes rebuild the 16 states of the group afterwards (all scalar work per frame).
+    uint32_t dec = 0;
+    auto bt_step = [&](const uint32_t (&w)[SPL], const int sh) __attribute__((always_inline)) {
+        const int ow = (int)((uint32_t)b / SPL), q = (int)((uint32_t)b % SPL);   // b >= 0 on every valid path
+        uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w[0], ow);
 #pragma unroll
-        for (int q = 0; q < SPL; q++) w[q] = bpw_base[(size_t)kb * SL + lane * SPL + q];
-        const int thi = (kb << 4) + 15 < T - 1 ? (kb << 4) + 15 : T - 1;
-        for (int t = thi; t >= (kb << 4); t--) {
-            if ((t & 63) == lane) pv = b;
-            const int ow = b / SPL, q = b % SPL;
-            uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w[0], ow);
-#pragma unroll
-            for (int qq = 1; qq < SPL; qq++) {
-                uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)w[qq], ow);
-                if (q == qq) word = cand;
-            }
-            b -= (int)((word >> (2 * (t & 15))) & 3u);
-            b = __builtin_amdgcn_readfirstlane(b);
-            if ((t & 63) == 0) {
-                // frames t .. t+63 (clipped) are complete
-                if (t + lane < T) path[f0 + t + lane] = pv;
-            }
+        for (int qq = 1; qq < SPL; qq++) {
+            uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)w[qq], ow);
+            if (q == qq) word = cand;
         }
+        const uint32_t field = word & (3u << sh);
+        dec |= field;
+        b -= (int)(field >> sh);
+    };
+    auto bt_flush = [&](const int ta0) __attribute__((always_inline)) {   // frames with t + a in ta0 .. ta0 + 63
+        const int t = ta0 - a + lane;
+        if (t >= 0 && t < T) path[f0 + t] = pv;
+    };
+    for (int c_hi = ng; c_hi > 0; c_hi -= BT_CH) {
+        const int c_lo = c_hi > BT_CH ? c_hi - BT_CH : 0;
+#pragma unroll 8
+        for (int g = c_lo; g < c_hi; g++) {
+#pragma unroll
+            for (int q = 0; q < SPL; q++) s_bp[(g - c_lo) * SL + q * 64 + lane] = bpw_base[(size_t)g * SL + q * 64 + lane];
+        }
+        __syncthreads();
+        uint32_t wn[SPL];
+#pragma unroll
+        for (int q = 0; q < SPL; q++) wn[q] = s_bp[(c_hi - 1 - c_lo) * SL + lane * SPL + q];
+        for (int kb = c_hi - 1; kb >= c_lo; kb--) {
+            uint32_t w[SPL];
+#pragma unroll
+            for (int q = 0; q < SPL; q++) w[q] = wn[q];
+            if (kb > c_lo) {
+#pragma unroll
+                for (int q = 0; q < SPL; q++) wn[q] = s_bp[(kb - 1 - c_lo) * SL + lane * SPL + q];
+            }
+            const int hi = (kb << 4) + 15 < T - 1 + a ? (kb << 4) + 15 : T - 1 + a;   // in units of t + a
+            const int lo = (kb << 4) > a ? (kb << 4) : a;
+            const int b_in = b;   // state of the group's last frame
+            dec = 0;
+            if (hi - lo == 15) {
+#pragma unroll
+                for (int j = 15; j >= 0; j--) bt_step(w, 2 * j);
+            } else {
+                for (int ta = hi; ta >= lo; ta--) bt_step(w, 2 * (ta & 15));
+            }
+            // state of frame j of the group = b_in - (sum of the decrements of frames j+1 .. 15); frames outside
+            // lo..hi have a zero field and are never stored
+            {
+                const int j = lane & 15;
+                const uint32_t above = (dec >> (2 * j)) >> 2;
+                const int sum = __builtin_popcount(above & 0x55555555u) + 2 * __builtin_popcount(above & 0xAAAAAAAAu);
+                if ((lane >> 4) == (kb & 3)) pv = b_in - sum;
+            }
+            if ((kb & 3) == 0) bt_flush(kb << 4);
+        }
+        __syncthreads();
     }
+#ifdef SRX_VIT_TIMING
+    if (lane == 0 && T >= 4) {
+        const long long tk3 = wall_clock64();
+        path[f0] = (int)(tk1 - tk0); path[f0 + 1] = (int)(tk2 - tk1); path[f0 + 2] = (int)(tk3 - tk2);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -360,7 +500,7 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
 #define SRX_VIT(SPLV, BEAMV)                                                                                              \
     do { if (vec) SRX_VIT2(SPLV, BEAMV, true); else SRX_VIT2(SPLV, BEAMV, false); } while (0)
 #define SRX_VIT2(SPLV, BEAMV, VECV)                                                                                       \
-    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, VECV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
+    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, VECV, (VECV ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF)>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
                        hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, ebase_dev, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
     {
