@@ -34,7 +34,7 @@ extern "C" int srx_align_plan_create(srx_ctx *ctx, const int64_t *frame_off, con
     for (int u = 0; u < n_utt; u++) {
         const int64_t T = frame_off[u + 1] - frame_off[u];
         const int64_t S = state_off[u + 1] - state_off[u];
-        if (T < 0 || S < 1 || T >= (1ll << 31)) {
+        if (T < 0 || S < 1 || T >= (1ll << 31) || S * T >= (1ll << 31)) {   // k_viterbi indexes a block with 32 bits
             delete p;
             return srx_fail(ctx, SRX_ERR_INVALID, "srx_align_plan_create: utterance %d has %lld frames, %lld states", u, (long long)T,
                             (long long)S);

@@ -48,12 +48,15 @@ static constexpr int NEVER = 0x7fffffff;
 // VEC: state-major dense emissions with 16-byte aligned rows (stride_t == 1, stride_g % 4 == 0): a lane fetches four
 // consecutive frames of its state's row per load -- a quarter of the load instructions and of the cache-line lookups
 // (64 lanes read 64 different rows).  The frame loop then starts at the aligned frame at or before the utterance's first.
-template <int SPL, bool BEAM, bool VEC, int PF>
+template <int SPL, bool BEAM, int LAY, int PF>
 __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                                 const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
                                                 const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
                                                 const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
                                                 float *__restrict__ final_logp, int32_t *__restrict__ status) {
+    // LAY: 0 = strided emission matrix, 1 = VEC (see above), 2 = compact per-utterance blocks [T][S] at ebase[u] (a
+    // frame's emissions are one contiguous row; the block has fewer than 2^31 entries, so offsets are 32-bit)
+    constexpr bool VEC = LAY == 1, COMPACT = LAY == 2;
     const int u = blockIdx.x;
     if (u >= n_utt) return;
     const int lane = threadIdx.x;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         col[q] = 0;
         act[q] = (s == 0);
         if (s < S) {
-            col[q] = ebase ? s : tied[s0 + s];   // compact per-utterance block: the row is the state itself
+            col[q] = COMPACT ? s : tied[s0 + s];   // compact per-utterance block: the row is the state itself
             a0[q] = trlogp[(size_t)(s0 + s) * 3];
             tv0[q] = dmin[s + 2];
             if (s >= 1 && s_ntr[s - 1] >= 2) {
@@ -128,16 +131,15 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         has2[q] = (s < S && s >= 2) ? s_ntr[s - 2] == 3 : false;
     }
 
-    // dense matrix: frame t of the batch, column tied[s]; compact (alignment-mode scoring): utterance block [T][S] at
-    // ebase[u] -- a frame's emissions are one contiguous row, one or two cache lines per wave load
-    if (ebase) {
-        st_t = S;
-        st_g = 1;
-    }
-    const float *erow = ebase ? emis + ebase[u] : emis + f0 * st_t;
+    // dense matrix: frame t of the batch, column tied[s]; compact: the utterance's own block
+    const float *erow = COMPACT ? emis + ebase[u] : emis + f0 * st_t;
     int64_t eoff[SPL];
 #pragma unroll
-    for (int q = 0; q < SPL; q++) eoff[q] = (int64_t)col[q] * st_g;
+    for (int q = 0; q < SPL; q++) eoff[q] = COMPACT ? (int64_t)col[q] : (int64_t)col[q] * st_g;
+    auto emission = [&](const int t, const int q) __attribute__((always_inline)) -> float {
+        if (COMPACT) return erow[(uint32_t)t * (uint32_t)S + (uint32_t)col[q]];
+        return erow[(int64_t)t * st_t + eoff[q]];
+    };
     float er[PF][SPL];
     const int a = VEC ? (int)(f0 & 3) : 0;                 // frames between the aligned start and the utterance's first
     const int tlast4 = VEC ? (int)(((f0 + T - 1) & ~(int64_t)3) - f0) : 0;   // aligned group holding the last frame
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         for (int p = 0; p < PF; p++) {
             const int tt = p < T ? p : (T > 0 ? T - 1 : 0);
 #pragma unroll
-            for (int q = 0; q < SPL; q++) er[p][q] = T > 0 ? erow[(int64_t)tt * st_t + eoff[q]] : 0.0f;
+            for (int q = 0; q < SPL; q++) er[p][q] = T > 0 ? emission(tt, q) : 0.0f;
         }
     }
 
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
                 int tn = t + PF;
                 if (tn >= T) tn = T - 1;
 #pragma unroll
-                for (int q = 0; q < SPL; q++) er[p][q] = erow[(int64_t)tn * st_t + eoff[q]];
+                for (int q = 0; q < SPL; q++) er[p][q] = emission(tn, q);
             }
             if (!GUARD || (t >= 0 && t < T)) {
                 bool ok[SPL];
@@ -296,7 +298,6 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
 #ifdef SRX_VIT_TIMING
     const long long tk1 = wall_clock64();
 #endif
-#ifndef SRX_VIT_NOLOOP
     // frame from which all threshold tests have settled (uniform over the wave)
     int t_static = 0;
     if (!BEAM) {
@@ -322,7 +323,6 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
             else run_block(std::integral_constant<int, 0>{}, tb);
         }
     }
-#endif
 
 #ifdef SRX_VIT_TIMING
     const long long tk2 = wall_clock64();
@@ -360,9 +360,6 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     // ---- backtrace (src/hmm.cpp:219-222): current state b is wave-uniform ----
     int b = last;
     int pv = 0;
-#ifdef SRX_VIT_NOBT
-    if (T > 0) return;
-#endif
     // The walk is one dependent chain per frame, so it must not wait on memory either: the back-pointer words come
     // into LDS a chunk of BT_CH groups (16 frames each) at a time with all loads in flight together, and the walk
     // reads the next group's registers from LDS while it steps through the current one.  Lane (t + a) & 63 of `pv`
@@ -498,9 +495,9 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     const bool vec = !ebase_dev && stride_t == 1 && stride_g % 4 == 0 && stride_g >= total_frames &&
                      (reinterpret_cast<uintptr_t>(emis_dev) & 15) == 0;
 #define SRX_VIT(SPLV, BEAMV)                                                                                              \
-    do { if (vec) SRX_VIT2(SPLV, BEAMV, true); else SRX_VIT2(SPLV, BEAMV, false); } while (0)
-#define SRX_VIT2(SPLV, BEAMV, VECV)                                                                                       \
-    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, VECV, (VECV ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF)>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
+    do { if (vec) SRX_VIT2(SPLV, BEAMV, 1); else if (ebase_dev) SRX_VIT2(SPLV, BEAMV, 2); else SRX_VIT2(SPLV, BEAMV, 0); } while (0)
+#define SRX_VIT2(SPLV, BEAMV, LAYV)                                                                                       \
+    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, LAYV, (LAYV == 1 ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF)>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
                        hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, ebase_dev, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
     {
