@@ -116,7 +116,7 @@ struct srx_model {
     uint64_t packed16_version = 0;
     int packed16_mode = -1;
     // frame-independent part of gaussian::operator(): lconst[o][d] = (double)(float)log(2/pi) + log(var[o][d])  (srx_train.hip)
-    double *lconst = nullptr;
+    double *lconst = nullptr;   // [G*M*D] lconst followed by [G*M*D] 1/var
     uint64_t lconst_version = 0;
     void *packed16s = nullptr;     // per-state form for alignment-mode scoring (srx_gmm_f16_align.hip)
     size_t packed16s_bytes = 0;
@@ -142,15 +142,18 @@ __device__ __forceinline__ float srx_logprob_exact(const float *__restrict__ fv,
     return h + logwt;
 }
 
-// The same value bit for bit, with the frame-independent sum (l2pi + log(var[i])) taken from a table.
+// The statistics form: the frame-independent sum (l2pi + log(var[i])) and the reciprocal of the variance come from
+// per-model tables, so the inner loop has no division and no log.  tt * (1 / var) differs from tt / var by at most one
+// ulp of the f64 quotient, 2^-29 of the f32 rounding applied to `res` on the next line (the reference divides in
+// 80-bit long double; neither f64 form reproduces that bit for bit).
 __device__ __forceinline__ float srx_logprob_exact_lc(const float *__restrict__ fv, const double *__restrict__ mean,
-                                                      const double *__restrict__ var, const double *__restrict__ lconst, float logwt,
+                                                      const double *__restrict__ rvar, const double *__restrict__ lconst, float logwt,
                                                       int D) {
     float res = 0.0f;
     for (int i = 0; i < D; i++) {
         float t = (float)((double)fv[i] - mean[i]);
         float tt = t * t;
-        double term = lconst[i] + (double)tt / var[i];
+        double term = lconst[i] + (double)tt * rvar[i];
         res = (float)((double)res + term);
     }
     float h = -0.5f * res;

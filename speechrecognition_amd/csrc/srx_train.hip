@@ -43,12 +43,15 @@ __global__ void k_fill_f32(float *p, float v, int n) {
 __global__ __launch_bounds__(256) void k_model_lconst(const double *__restrict__ var, int64_t n, double *__restrict__ lconst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const float l2pi = (float)-0.4515827052894549;  // (float)log(M_2_PI), src/gmm.cpp:43
-    if (i < n) lconst[i] = (double)l2pi + log(var[i]);
+    if (i < n) {
+        lconst[i] = (double)l2pi + log(var[i]);
+        lconst[n + i] = 1.0 / var[i];
+    }
 }
 
 // one thread per (frame, component): log-density under A, and the per-state maximum
 __global__ __launch_bounds__(256) void k_em_logp(const float *__restrict__ feats, int ld, const int32_t *__restrict__ gid, int64_t T,
-                                                 int M, int D, const double *__restrict__ mean, const double *__restrict__ var,
+                                                 int M, int D, const double *__restrict__ mean, const double *__restrict__ rvar,
                                                  const double *__restrict__ lconst, const float *__restrict__ logwt,
                                                  float *__restrict__ logp, float *__restrict__ shift) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void k_em_logp(const float *__restrict__ feats
     const int g = gid[t];
     if (g < 0) { logp[idx] = 0.0f; return; }
     const size_t o = (size_t)g * M + m;
-    const float lp = srx_logprob_exact_lc(feats + t * ld, mean + o * D, var + o * D, lconst + o * D, logwt[o], D);
+    const float lp = srx_logprob_exact_lc(feats + t * ld, mean + o * D, rvar + o * D, lconst + o * D, logwt[o], D);
     logp[idx] = lp;
     if (lp == lp) atomic_max_float(&shift[o], lp);
 }
@@ -217,7 +220,7 @@ extern "C" int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
 
 // srx_train_seg.hip: sort-by-state segmented reduction for tables beyond LDS
 bool srx_em_seg_applicable(int M, int D);
-int srx_em_logp_seg(srx_ctx *ctx, const float *feats, int ld, int64_t T, int G, int M, int D, const double *mean, const double *var,
+int srx_em_logp_seg(srx_ctx *ctx, const float *feats, int ld, int64_t T, int G, int M, int D, const double *mean, const double *rvar,
                     const double *lconst, const float *logwt, float *logp, float *shift);
 int srx_em_seg_sort(srx_ctx *ctx, const int32_t *gid, int64_t T, int G);
 template <int PASS>
@@ -244,7 +247,7 @@ extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
     }
     if (A->lconst_version != A->version || !A->lconst) {
         const int64_t nl = (int64_t)A->G * A->M * A->D;
-        if (!A->lconst) SRX_HIP(ctx, hipMalloc((void **)&A->lconst, (size_t)nl * sizeof(double)));
+        if (!A->lconst) SRX_HIP(ctx, hipMalloc((void **)&A->lconst, (size_t)2 * nl * sizeof(double)));
         {
             SrxProf prof_(ctx, "k_model_lconst");
             hipLaunchKernelGGL(k_model_lconst, dim3((unsigned)ceil_div64(nl, 256)), dim3(256), 0, ctx->stream, A->var, nl, A->lconst);
@@ -253,13 +256,14 @@ extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
         A->lconst_version = A->version;
     }
     if (seg)
-        return srx_em_logp_seg(ctx, feats_dev, ld, T, A->G, A->M, A->D, A->mean, A->var, A->lconst, A->logwt, logp_dev, shift_dev);
+        return srx_em_logp_seg(ctx, feats_dev, ld, T, A->G, A->M, A->D, A->mean, A->lconst + (size_t)A->G * A->M * A->D, A->lconst, A->logwt,
+                               logp_dev, shift_dev);
     const int64_t n = T * A->M;
     SRX_REQUIRE(ctx, ceil_div64(n, 256) < (1ll << 31), "srx_em_shift_dev: too large");
     {
         SrxProf prof_(ctx, "k_em_logp");
         hipLaunchKernelGGL(k_em_logp, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, feats_dev, ld, gid_dev, T, A->M, A->D,
-                           A->mean, A->var, A->lconst, A->logwt, logp_dev, shift_dev);
+                           A->mean, A->lconst + (size_t)A->G * A->M * A->D, A->lconst, A->logwt, logp_dev, shift_dev);
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;

@@ -81,6 +81,10 @@ __global__ __launch_bounds__(1024) void k_em_item_scan(const int64_t *__restrict
 
 // One work item = up to CH frames of one state.  PASS 1: sums [zeta, zeta*x_d]; PASS 2: [zeta*diff_d^2],
 // diff = f32(x_d - meanB[o][d]) (src/hmm.cpp:331).  partial[item][M*stride].
+// Thread = (component m = tid / 16, column dq = tid % 16) with the row elements e = dq, dq + 16, dq + 32, dq + 48 of
+// that component in registers: one zeta read serves all of a thread's sums, the staged values are already f64, and
+// the frame loop is unrolled.  Sums run in frame order, one fused multiply-add per term (f64; the reference sums in
+// 80-bit long double, src/hmm.cpp:285-334).
 template <int PASS>
 __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
                                                       const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
                                                       const float *__restrict__ shift, const double *__restrict__ meanB,
                                                       double *__restrict__ partial) {
     __shared__ double zeta[FB][16];
-    __shared__ float xv[FB][64];
+    __shared__ double xv[FB][65];   // PASS 1: [1, x_0 .. x_{D-1}]; PASS 2: [x_0 .. x_{D-1}]
     __shared__ int ft[FB];
     const int item = blockIdx.x;
     if (item >= item_start[G]) return;
@@ -102,70 +106,72 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
     const int64_t p1 = p0 + CH < start[g + 1] ? p0 + CH : start[g + 1];
     const int stride = PASS == 1 ? 1 + D : D;
     const int R = M * stride;
-    double acc[ACC_MAX];
-    double mb[ACC_MAX];
-    int am[ACC_MAX], ae[ACC_MAX];
+    const int m = threadIdx.x >> 4, dq = threadIdx.x & 15;
+    double acc[ACC_MAX], mb[ACC_MAX];
+    bool live[ACC_MAX];
 #pragma unroll
     for (int a = 0; a < ACC_MAX; a++) {
-        const int idx = threadIdx.x + a * 256;
+        const int e = dq + 16 * a;
         acc[a] = 0.0;
-        am[a] = idx < R ? idx / stride : 0;
-        ae[a] = idx < R ? idx % stride : 0;
-        mb[a] = (PASS == 2 && idx < R) ? meanB[((size_t)g * M + am[a]) * D + ae[a]] : 0.0;
+        live[a] = m < M && e < stride;
+        mb[a] = (PASS == 2 && live[a]) ? meanB[((size_t)g * M + m) * D + e] : 0.0;
     }
+    for (int i = threadIdx.x; i < FB * 16; i += 256) (&zeta[0][0])[i] = 0.0;   // components >= M and the tail frames stay 0
     for (int64_t p = p0; p < p1; p += FB) {
         const int nf = p1 - p < FB ? (int)(p1 - p) : FB;
         __syncthreads();   // the previous step's reads are done
         if (threadIdx.x < nf) ft[threadIdx.x] = order[p + threadIdx.x];
         __syncthreads();
-        for (int i = threadIdx.x; i < nf * M; i += 256) {
-            const int f = i / M, m = i - f * M;
-            const size_t o = (size_t)g * M + m;
-            // zeta = weight * prob (src/hmm.cpp:282,307,328), shifted
-            zeta[f][m] = (double)weight[o] * exp((double)logp[(int64_t)ft[f] * M + m] - (double)shift[o]);
+        for (int i = threadIdx.x; i < FB * M; i += 256) {
+            const int f = i / M, mm = i - f * M;
+            const size_t o = (size_t)g * M + mm;
+            // zeta = weight * prob (src/hmm.cpp:282,307,328), shifted; frames past the item's end contribute 0
+            zeta[f][mm] = f < nf ? (double)weight[o] * exp((double)logp[(int64_t)ft[f] * M + mm] - (double)shift[o]) : 0.0;
         }
-        for (int i = threadIdx.x; i < nf * D; i += 256) {
-            const int f = i / D, d = i - f * D;
-            xv[f][d] = feats[(int64_t)ft[f] * ld + d];
+        for (int i = threadIdx.x; i < FB * stride; i += 256) {
+            const int f = i / stride, e = i - f * stride;
+            double v = 0.0;
+            if (f < nf) v = (PASS == 1 && e == 0) ? 1.0 : (double)feats[(int64_t)ft[f] * ld + (PASS == 1 ? e - 1 : e)];
+            xv[f][e] = v;
         }
         __syncthreads();
+#pragma unroll 8
+        for (int f = 0; f < FB; f++) {
+            const double z = zeta[f][m];
 #pragma unroll
-        for (int a = 0; a < ACC_MAX; a++) {
-            if (threadIdx.x + a * 256 < R) {
-                const int m = am[a], e = ae[a];
-                double s = acc[a];
-                if (PASS == 1) {
-                    if (e == 0) {
-                        for (int f = 0; f < nf; f++) s += zeta[f][m];
+            for (int a = 0; a < ACC_MAX; a++) {
+                if (live[a]) {
+                    const double x = xv[f][dq + 16 * a];
+                    if (PASS == 1) {
+                        acc[a] = fma(z, x, acc[a]);
                     } else {
-                        for (int f = 0; f < nf; f++) s += zeta[f][m] * (double)xv[f][e - 1];
-                    }
-                } else {
-                    for (int f = 0; f < nf; f++) {
-                        const float diff = (float)((double)xv[f][e] - mb[a]);
-                        s += zeta[f][m] * (double)diff * (double)diff;
+                        const float diff = (float)(x - mb[a]);
+                        acc[a] = fma(z * (double)diff, (double)diff, acc[a]);
                     }
                 }
-                acc[a] = s;
             }
         }
     }
 #pragma unroll
     for (int a = 0; a < ACC_MAX; a++)
-        if (threadIdx.x + a * 256 < R) partial[(size_t)item * R + threadIdx.x + a * 256] = acc[a];
+        if (live[a]) partial[(size_t)item * R + m * stride + dq + 16 * a] = acc[a];
 }
 
 // Log-densities of the aligned frames under A in sorted order: a work item's state parameters sit in LDS and the item's
 // frames stream past them (the frame-order kernel k_em_logp gathers 780 bytes of parameters per (frame, component)
-// through L2).  Same routine, same bits (srx_logprob_exact_lc).  shift[o] = max over the frames of component o.
+// through L2).  Same arithmetic as srx_logprob_exact_lc, statement for statement.  A thread owns one component and
+// LP_FPT frames of each 64-frame step, so every parameter triple read from LDS serves LP_FPT frames.
+// shift[o] = max over the frames of component o.
+static constexpr int LP_FPT = 4;           // frames per thread and step
+static constexpr int LP_STEP = 16 * LP_FPT;  // frames per step
 __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
                                                      const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
-                                                     int M, int D, const double *__restrict__ mean, const double *__restrict__ var,
+                                                     int M, int D, const double *__restrict__ mean, const double *__restrict__ rvar,
                                                      const double *__restrict__ lconst, const float *__restrict__ logwt,
                                                      float *__restrict__ logp, float *__restrict__ shift) {
-    extern __shared__ double par[];          // mean[M][D], var[M][D], lconst[M][D]
-    __shared__ float xs[16][64];             // 16 frames per step
-    __shared__ int fts[16];
+    extern __shared__ double par[];          // mean[M][D], rvar[M][D], lconst[M][D]
+    __shared__ float xs[LP_STEP][65];        // one step's feature rows (D <= 64)
+    __shared__ int fts[LP_STEP];
     __shared__ float smax[16];
     const int item = blockIdx.x;
     if (item >= item_start[G]) return;
@@ -178,19 +184,19 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
     const int64_t p0 = start[g] + (int64_t)(item - item_start[g]) * CH;
     const int64_t p1 = p0 + CH < start[g + 1] ? p0 + CH : start[g + 1];
     const int MD = M * D;
-    double *pm = par, *pv = par + MD, *pl = par + 2 * MD;
+    double *pm = par, *pr = par + MD, *pl = par + 2 * MD;
     for (int i = threadIdx.x; i < MD; i += 256) {
         pm[i] = mean[(size_t)g * MD + i];
-        pv[i] = var[(size_t)g * MD + i];
+        pr[i] = rvar[(size_t)g * MD + i];
         pl[i] = lconst[(size_t)g * MD + i];
     }
     if (threadIdx.x < 16) smax[threadIdx.x] = -__builtin_huge_valf();
-    // thread = (frame slot f = tid / 16, component m = tid % 16): 16 frames x 16 components per step
+    // thread = (frame slot f = tid / 16, component m = tid % 16); its frames in a step are f, f + 16, f + 32, f + 48
     const int f = threadIdx.x >> 4, m = threadIdx.x & 15;
     const float lw = m < M ? logwt[(size_t)g * M + m] : 0.0f;
     float mymax = -__builtin_huge_valf();
-    for (int64_t p = p0; p < p1; p += 16) {
-        const int nf = p1 - p < 16 ? (int)(p1 - p) : 16;
+    for (int64_t p = p0; p < p1; p += LP_STEP) {
+        const int nf = p1 - p < LP_STEP ? (int)(p1 - p) : LP_STEP;
         __syncthreads();
         if (threadIdx.x < nf) fts[threadIdx.x] = order[p + threadIdx.x];
         __syncthreads();
@@ -199,10 +205,30 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
             xs[ff][d] = feats[(int64_t)fts[ff] * ld + d];
         }
         __syncthreads();
-        if (f < nf && m < M) {
-            const float lp = srx_logprob_exact_lc(xs[f], pm + m * D, pv + m * D, pl + m * D, lw, D);
-            logp[(int64_t)fts[f] * M + m] = lp;
-            if (lp == lp) mymax = fmaxf(mymax, lp);
+        if (m < M) {
+            float res[LP_FPT];
+#pragma unroll
+            for (int k = 0; k < LP_FPT; k++) res[k] = 0.0f;
+            const double *qm = pm + m * D, *qr = pr + m * D, *ql = pl + m * D;
+            for (int i = 0; i < D; i++) {
+                const double mu = qm[i], rv = qr[i], lc = ql[i];
+#pragma unroll
+                for (int k = 0; k < LP_FPT; k++) {
+                    const float t = (float)((double)xs[f + 16 * k][i] - mu);
+                    const float tt = t * t;
+                    const double term = lc + (double)tt * rv;
+                    res[k] = (float)((double)res[k] + term);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < LP_FPT; k++) {
+                if (f + 16 * k < nf) {
+                    const float h = -0.5f * res[k];
+                    const float lp = h + lw;
+                    logp[(int64_t)fts[f + 16 * k] * M + m] = lp;
+                    if (lp == lp) mymax = fmaxf(mymax, lp);
+                }
+            }
         }
     }
     // per-component maximum of this item -> shift (float max through the ordered-int trick of k_em_logp)
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(256) void k_em_logp_skipped(const int32_t *__restri
     for (int m = 0; m < M; m++) logp[t * M + m] = 0.0f;
 }
 
-int srx_em_logp_seg(srx_ctx *ctx, const float *feats, int ld, int64_t T, int G, int M, int D, const double *mean, const double *var,
+int srx_em_logp_seg(srx_ctx *ctx, const float *feats, int ld, int64_t T, int G, int M, int D, const double *mean, const double *rvar,
                     const double *lconst, const float *logwt, float *logp, float *shift) {
     EmSortView v;
     em_sort_view(ctx->ws[2], T, G, &v);
@@ -241,7 +267,7 @@ int srx_em_logp_seg(srx_ctx *ctx, const float *feats, int ld, int64_t T, int G, 
     {
         SrxProf prof_(ctx, "k_em_logp_seg");
         hipLaunchKernelGGL(k_em_logp_seg, dim3((unsigned)max_items), dim3(256), (size_t)3 * M * D * sizeof(double), ctx->stream, feats, ld, v.order,
-                           v.start, v.item_start, G, M, D, mean, var, lconst, logwt, logp, shift);
+                           v.start, v.item_start, G, M, D, mean, rvar, lconst, logwt, logp, shift);
     }
     SRX_LAUNCH_CHECK(ctx);
     {
@@ -264,7 +290,7 @@ __global__ __launch_bounds__(256) void k_em_seg_reduce(const int32_t *__restrict
     }
 }
 
-bool srx_em_seg_applicable(int M, int D) { return M <= 16 && D <= 63 && M * (1 + D) <= 256 * ACC_MAX; }
+bool srx_em_seg_applicable(int M, int D) { return M <= 16 && D <= 63; }   // 16 x 64 sums in 256 threads x ACC_MAX
 
 // Sorts the frames of alignment `gid` by state into workspace slot 2 (kept until the next sort).
 int srx_em_seg_sort(srx_ctx *ctx, const int32_t *gid, int64_t T, int G) {

@@ -21,6 +21,9 @@ def main():
     args = ap.parse_args()
     import torch
     torch.cuda.init()
+    from speechrecognition_amd import _capi
+    if os.environ.get("SRX_LIB"):
+        _capi.LIB_PATH = os.path.abspath(os.environ["SRX_LIB"])   # A/B a variant build
     from speechrecognition_amd import SRX_MIX_LOGSUMEXP, host, parallel, synth
     from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3
     G, M, D = 2000, 16, 39
