@@ -217,7 +217,8 @@ int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
  * reference computes lazily inside hmm::viterbi (src/hmm.cpp:166, (*acm)(*fvs[i], target->ctx) for the targets of the
  * active states) -- instead of the dense [T][G] matrix of srx_gmm_score_dev.  The plan (host frame/state offsets of the
  * batch) fixes the compact layout: utterance u owns emis[off[u] .. off[u+1]) as a frame-major block [T_u][S_u]
- * (emis[off[u] + t*S_u + s]), off[u+1] - off[u] = S_u * T_u.  Scores are bit-identical to srx_gmm_score_dev's on the same path.
+ * (emis[off[u] + t*S_u + s]), off[u+1] - off[u] = S_u * T_u < 2^31 (plan creation rejects a larger block: the alignment
+ * kernel indexes inside a block with 32 bits).  Scores are bit-identical to srx_gmm_score_dev's on the same path.
  * score_path: SRX_SCORE_MFMA_F16X3 (models f16 cannot hold are evaluated exactly instead) or SRX_SCORE_EXACT. */
 typedef struct srx_align_plan srx_align_plan;
 int srx_align_plan_create(srx_ctx *ctx, const int64_t *frame_off, const int32_t *state_off, int n_utt, srx_align_plan **out);
@@ -256,7 +257,9 @@ int srx_state_model_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *c
  * Call them in this order for every new alignment: step 1 also sorts the frames by state when the table is too
  * large for LDS (then passes 2 and 4 are atomics-free segmented reductions, deterministic in frame order).
  * zeta is computed as w*exp(logp - shift[g][m]) in f64 (the reference uses unshifted 80-bit values;
- * every quantity it derives from them is a ratio in which the shift cancels or is re-applied). */
+ * every quantity it derives from them is a ratio in which the shift cancels or is re-applied).  The log-densities of
+ * step 1 follow gaussian::operator() (src/gmm.cpp:41-49) term by term in f64 with the division by the variance as a
+ * multiplication by its f64 reciprocal (the reference divides in 80-bit long double). */
 int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,
                           const int32_t *status_dev, int64_t total_frames, int32_t *gid_dev);
 int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
