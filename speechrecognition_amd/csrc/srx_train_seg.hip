@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) void k_em_item_scan(const int64_t *__restrict
 // that component in registers: one zeta read serves all of a thread's sums, the staged values are already f64, and
 // the frame loop is unrolled.  Sums run in frame order, one fused multiply-add per term (f64; the reference sums in
 // 80-bit long double, src/hmm.cpp:285-334).
-template <int PASS>
+template <int PASS, int NACC>
 __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
                                                       const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
                                                       int M, int D, const float *__restrict__ weight, const float *__restrict__ logp,
@@ -107,10 +107,10 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
     const int stride = PASS == 1 ? 1 + D : D;
     const int R = M * stride;
     const int m = threadIdx.x >> 4, dq = threadIdx.x & 15;
-    double acc[ACC_MAX], mb[ACC_MAX];
-    bool live[ACC_MAX];
+    double acc[NACC], mb[NACC];
+    bool live[NACC];   // NACC = ceil(stride / 16): only the last accumulator can be past the row's end
 #pragma unroll
-    for (int a = 0; a < ACC_MAX; a++) {
+    for (int a = 0; a < NACC; a++) {
         const int e = dq + 16 * a;
         acc[a] = 0.0;
         live[a] = m < M && e < stride;
@@ -139,21 +139,20 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
         for (int f = 0; f < FB; f++) {
             const double z = zeta[f][m];
 #pragma unroll
-            for (int a = 0; a < ACC_MAX; a++) {
-                if (live[a]) {
-                    const double x = xv[f][dq + 16 * a];
-                    if (PASS == 1) {
-                        acc[a] = fma(z, x, acc[a]);
-                    } else {
-                        const float diff = (float)(x - mb[a]);
-                        acc[a] = fma(z * (double)diff, (double)diff, acc[a]);
-                    }
+            for (int a = 0; a < NACC; a++) {
+                // no test on live[a] here: a dead accumulator sums staged garbage that is never stored
+                const double x = xv[f][dq + 16 * a];
+                if (PASS == 1) {
+                    acc[a] = fma(z, x, acc[a]);
+                } else {
+                    const float diff = (float)(x - mb[a]);
+                    acc[a] = fma(z * (double)diff, (double)diff, acc[a]);
                 }
             }
         }
     }
 #pragma unroll
-    for (int a = 0; a < ACC_MAX; a++)
+    for (int a = 0; a < NACC; a++)
         if (live[a]) partial[(size_t)item * R + m * stride + dq + 16 * a] = acc[a];
 }
 
@@ -349,7 +348,9 @@ int srx_em_accum_seg(srx_ctx *ctx, const float *feats, int ld, const int32_t *gi
     if (rc != SRX_OK) return rc;
     {
         SrxProf prof_(ctx, PASS == 1 ? "k_em_accum_seg1" : "k_em_accum_seg2");
-        hipLaunchKernelGGL((k_em_accum_seg<PASS>), dim3((unsigned)max_items), dim3(256), 0, ctx->stream, feats, ld, v.order, v.start,
+        const int nacc = ((PASS == 1 ? 1 + D : D) + 15) / 16;
+        auto kern = nacc <= 1 ? k_em_accum_seg<PASS, 1> : nacc == 2 ? k_em_accum_seg<PASS, 2> : nacc == 3 ? k_em_accum_seg<PASS, 3> : k_em_accum_seg<PASS, 4>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)max_items), dim3(256), 0, ctx->stream, feats, ld, v.order, v.start,
                            v.item_start, G, M, D, weight, logp, shift, meanB, (double *)pw);
     }
     SRX_LAUNCH_CHECK(ctx);
