@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
                                                       double *__restrict__ partial) {
     __shared__ double zeta[FB][16];
     __shared__ double xv[FB][65];   // PASS 1: [1, x_0 .. x_{D-1}]; PASS 2: [x_0 .. x_{D-1}]
-    __shared__ int ft[FB];
+    __shared__ int ft[2][FB];
     const int item = blockIdx.x;
     if (item >= item_start[G]) return;
     int lo = 0, hi = G;   // item_start[lo] <= item < item_start[hi]
@@ -117,24 +117,65 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
         mb[a] = (PASS == 2 && live[a]) ? meanB[((size_t)g * M + m) * D + e] : 0.0;
     }
     for (int i = threadIdx.x; i < FB * 16; i += 256) (&zeta[0][0])[i] = 0.0;   // components >= M and the tail frames stay 0
-    for (int64_t p = p0; p < p1; p += FB) {
-        const int nf = p1 - p < FB ? (int)(p1 - p) : FB;
-        __syncthreads();   // the previous step's reads are done
-        if (threadIdx.x < nf) ft[threadIdx.x] = order[p + threadIdx.x];
-        __syncthreads();
-        for (int i = threadIdx.x; i < FB * M; i += 256) {
+    // The step's inputs are gathered one step ahead into registers (each thread's share of the FB x M log-densities
+    // and the FB x stride feature values), so their latency passes under the previous step's sums instead of in
+    // front of a barrier; the frame indices run one step further ahead still (register, then LDS).
+    constexpr int NZ = 2;   // FB * M / 256 with M <= 16
+    constexpr int NX = 8;   // FB * stride / 256 with stride <= 64
+    float zr[NZ], xr[NX];
+    double zw[NZ], zs[NZ];  // weight and shift of the components this thread stages
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+        const int i = threadIdx.x + 256 * k;
+        const int mm = i % M;
+        zw[k] = i < FB * M ? (double)weight[(size_t)g * M + mm] : 0.0;
+        zs[k] = i < FB * M ? (double)shift[(size_t)g * M + mm] : 0.0;
+    }
+    auto gather = [&](int buf, int nf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+            const int i = threadIdx.x + 256 * k;
             const int f = i / M, mm = i - f * M;
-            const size_t o = (size_t)g * M + mm;
-            // zeta = weight * prob (src/hmm.cpp:282,307,328), shifted; frames past the item's end contribute 0
-            zeta[f][mm] = f < nf ? (double)weight[o] * exp((double)logp[(int64_t)ft[f] * M + mm] - (double)shift[o]) : 0.0;
+            zr[k] = (i < FB * M && f < nf) ? logp[(int64_t)ft[buf][f] * M + mm] : 0.0f;
         }
-        for (int i = threadIdx.x; i < FB * stride; i += 256) {
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int i = threadIdx.x + 256 * k;
             const int f = i / stride, e = i - f * stride;
-            double v = 0.0;
-            if (f < nf) v = (PASS == 1 && e == 0) ? 1.0 : (double)feats[(int64_t)ft[f] * ld + (PASS == 1 ? e - 1 : e)];
-            xv[f][e] = v;
+            float v = 0.0f;
+            if (i < FB * stride && f < nf && !(PASS == 1 && e == 0)) v = feats[(int64_t)ft[buf][f] * ld + (PASS == 1 ? e - 1 : e)];
+            xr[k] = v;
         }
+    };
+    const int64_t nsteps = (p1 - p0 + FB - 1) / FB;
+    auto frames_of = [&](int64_t s) { const int64_t r = p1 - (p0 + s * FB); return r < FB ? (int)(r < 0 ? 0 : r) : FB; };
+    int ord = 0;
+    if (threadIdx.x < frames_of(0)) ft[0][threadIdx.x] = order[p0 + threadIdx.x];
+    if (threadIdx.x < frames_of(1)) ord = order[p0 + FB + threadIdx.x];
+    __syncthreads();
+    gather(0, frames_of(0));
+    for (int64_t st = 0; st < nsteps; st++) {
+        const int nf = frames_of(st);
+        __syncthreads();   // the previous step's reads of zeta / xv are done
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+            const int i = threadIdx.x + 256 * k;
+            const int f = i / M, mm = i - f * M;
+            // zeta = weight * prob (src/hmm.cpp:282,307,328), shifted; frames past the item's end contribute 0
+            if (i < FB * M) zeta[f][mm] = f < nf ? zw[k] * exp((double)zr[k] - zs[k]) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int i = threadIdx.x + 256 * k;
+            const int f = i / stride, e = i - f * stride;
+            if (i < FB * stride) xv[f][e] = f < nf ? ((PASS == 1 && e == 0) ? 1.0 : (double)xr[k]) : 0.0;
+        }
+        if (threadIdx.x < frames_of(st + 1)) ft[(st + 1) & 1][threadIdx.x] = ord;
         __syncthreads();
+        if (st + 1 < nsteps) {
+            gather((int)((st + 1) & 1), frames_of(st + 1));
+            if (threadIdx.x < frames_of(st + 2)) ord = order[p0 + (st + 2) * FB + threadIdx.x];
+        }
 #pragma unroll 8
         for (int f = 0; f < FB; f++) {
             const double z = zeta[f][m];
