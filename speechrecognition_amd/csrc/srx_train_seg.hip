@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
                                                      float *__restrict__ logp, float *__restrict__ shift) {
     extern __shared__ double par[];          // mean[M][D], rvar[M][D], lconst[M][D]
     __shared__ float xs[LP_STEP][65];        // one step's feature rows (D <= 64)
-    __shared__ int fts[LP_STEP];
+    __shared__ int fts[2][LP_STEP];
     __shared__ float smax[16];
     const int item = blockIdx.x;
     if (item >= item_start[G]) return;
@@ -235,16 +235,41 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
     const int f = threadIdx.x >> 4, m = threadIdx.x & 15;
     const float lw = m < M ? logwt[(size_t)g * M + m] : 0.0f;
     float mymax = -__builtin_huge_valf();
-    for (int64_t p = p0; p < p1; p += LP_STEP) {
-        const int nf = p1 - p < LP_STEP ? (int)(p1 - p) : LP_STEP;
-        __syncthreads();
-        if (threadIdx.x < nf) fts[threadIdx.x] = order[p + threadIdx.x];
-        __syncthreads();
-        for (int i = threadIdx.x; i < nf * D; i += 256) {
+    // The feature rows of a step are gathered one step ahead into registers and the frame indices one step further
+    // (as in k_em_accum_seg): no barrier waits on a gather.
+    constexpr int NXR = (LP_STEP * 64 + 255) / 256;   // LP_STEP * D / 256 with D <= 64
+    float xr[NXR];
+    auto gather = [&](int buf, int nf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NXR; k++) {
+            const int i = threadIdx.x + 256 * k;
             const int ff = i / D, d = i - ff * D;
-            xs[ff][d] = feats[(int64_t)fts[ff] * ld + d];
+            xr[k] = (i < LP_STEP * D && ff < nf) ? feats[(int64_t)fts[buf][ff] * ld + d] : 0.0f;
         }
+    };
+    const int64_t nsteps = (p1 - p0 + LP_STEP - 1) / LP_STEP;
+    auto frames_of = [&](int64_t s_) { const int64_t r = p1 - (p0 + s_ * LP_STEP); return r < LP_STEP ? (int)(r < 0 ? 0 : r) : LP_STEP; };
+    int ord = 0;
+    if (threadIdx.x < frames_of(0)) fts[0][threadIdx.x] = order[p0 + threadIdx.x];
+    if (threadIdx.x < frames_of(1)) ord = order[p0 + LP_STEP + threadIdx.x];
+    __syncthreads();
+    gather(0, frames_of(0));
+    for (int64_t st = 0; st < nsteps; st++) {
+        const int nf = frames_of(st);
+        const int cur = (int)(st & 1);
+        __syncthreads();   // the previous step's reads of xs are done
+#pragma unroll
+        for (int k = 0; k < NXR; k++) {
+            const int i = threadIdx.x + 256 * k;
+            const int ff = i / D, d = i - ff * D;
+            if (i < LP_STEP * D) xs[ff][d] = xr[k];
+        }
+        if (threadIdx.x < frames_of(st + 1)) fts[cur ^ 1][threadIdx.x] = ord;
         __syncthreads();
+        if (st + 1 < nsteps) {
+            gather(cur ^ 1, frames_of(st + 1));
+            if (threadIdx.x < frames_of(st + 2)) ord = order[p0 + (st + 2) * LP_STEP + threadIdx.x];
+        }
         if (m < M) {
             float res[LP_FPT];
 #pragma unroll
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
                 if (f + 16 * k < nf) {
                     const float h = -0.5f * res[k];
                     const float lp = h + lw;
-                    logp[(int64_t)fts[f + 16 * k] * M + m] = lp;
+                    logp[(int64_t)fts[cur][f + 16 * k] * M + m] = lp;
                     if (lp == lp) mymax = fmaxf(mymax, lp);
                 }
             }
