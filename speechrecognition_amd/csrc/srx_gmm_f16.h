@@ -78,6 +78,37 @@ __device__ __forceinline__ f16x8 prep16_frag(const float *__restrict__ feats, in
     return out;
 }
 
+// The high and the low fragment of the same eight k at once, same arithmetic as prep16_frag.  Every load is
+// unconditional (indices clamped, validity applied to the values), so a caller that builds many fragments gets all
+// their loads in flight together instead of one dependent load-wait-compute chain per fragment.
+__device__ __forceinline__ void prep16_frag2(const float *__restrict__ feats, int ld, int64_t t, bool valid, int D, int k0,
+                                             const float *__restrict__ cs, bool &bad, f16x8 &hi, f16x8 &lo) {
+    float x[4], c0[4], c1[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int d = (k0 >> 1) + e;
+        const int dc = d < D ? d : D - 1;
+        x[e] = feats[t * ld + dc];
+        c0[e] = cs[dc];
+        c1[e] = cs[2 * D + dc];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int k = k0 + 2 * e;
+        const float lv = (x[e] - c0[e]) * c1[e];
+        const bool isdim = valid && k < 2 * D;
+        const bool over = isdim && !(fabsf(lv) <= kFrameLimit);   // also catches NaN
+        bad = bad || over;
+        const float l = (isdim && !over) ? lv : 0.0f;
+        const float q = (valid && k == 2 * D) ? 1.0f : l * l;
+        const _Float16 qh = (_Float16)q, lh = (_Float16)l;
+        hi[2 * e] = qh;
+        hi[2 * e + 1] = lh;
+        lo[2 * e] = (_Float16)(q - (float)qh);
+        lo[2 * e + 1] = (_Float16)(l - (float)lh);
+    }
+}
+
 // Per-(MP) tiling constants shared by the kernel and its launcher.
 template <int MP>
 struct F16Cfg {

@@ -215,10 +215,7 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
         const int64_t t = f0 + (valid ? lf : 0);
         bool bad = false;
 #pragma unroll
-        for (int s = 0; s < KS2; s++) {
-            const bool lo = s >= KS;
-            Bf[f][s] = prep16_frag(feats, ld, t, valid, D, (lo ? s - KS : s) * 16 + hh * 8, lo, cs, bad);
-        }
+        for (int s = 0; s < KS; s++) prep16_frag2(feats, ld, t, valid, D, s * 16 + hh * 8, cs, bad, Bf[f][s], Bf[f][KS + s]);
         if (bad) fflag[t] = 1;
     }
 
