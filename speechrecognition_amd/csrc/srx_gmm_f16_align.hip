@@ -278,7 +278,9 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
             if constexpr (i >= 1 && i <= KS2) {
                 asm volatile("" : "+v"(pn));
                 constexpr int s2 = i - 1 < KS ? KS + i - 1 : i - 1 - KS;   // lo fragments first, as they are used first
-                Afn[s2] = pn[s2 * MP * 2];
+                // the pin hides where pn points; without the address space the loads become FLAT ones, which count
+                // on both memory counters and made every tile wait for its own prefetch
+                Afn[s2] = ((const __attribute__((address_space(1))) f16x8 *)pn)[s2 * MP * 2];
             }
             if constexpr (i == KS2 + 1) g2 = state_of(n + 2);
             epi_slice(ic, accp, n - 1);
