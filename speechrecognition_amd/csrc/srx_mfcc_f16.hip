@@ -181,49 +181,53 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mfcc_f16(Mfcc16Args a) {
     {
         float ymax = 0.0f;
         float y[KS][8];
+        // All sample loads first, unconditionally: an invalid lane reads frame 0 of the batch (xu = x, p0 = 0) and a
+        // k-step past the half window reads on inside the frame's own window (16 KS <= window), so every address is
+        // inside the buffer; validity is applied to the values.  Inside `if` bodies the loads of the 13 k-steps became
+        // 13 dependent load-wait chains.
+        f4u A[KS], B[KS];
+        float C[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int64_t base = p0 + 16 * s + 8 * hh;
+            // nine consecutive samples x[base-1 .. base+7] as two 128-bit loads and one 32-bit load (4-byte alignment is
+            // enough for global_load_dwordx4); the first frame of an utterance has no x[-1]: it loads x[0 .. 8] and shifts
+            const bool at0 = s == 0 && base == 0;
+            const float *src = xu + (at0 ? 0 : base - 1);
+            A[s] = *reinterpret_cast<const f4u *>(src);
+            B[s] = *reinterpret_cast<const f4u *>(src + 4);
+            C[s] = src[8];
+        }
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const int n0 = 16 * s + 8 * hh;
-            const int64_t base = p0 + n0;
-            if (valid && n0 < a.half) {
-                // nine consecutive samples x[base-1 .. base+7] as two 128-bit loads and one 32-bit load (4-byte alignment is
-                // enough for global_load_dwordx4); the first frame of an utterance has no x[-1]: it loads x[0 .. 8] and shifts
-                const bool at0 = base == 0;
-                const float *src = xu + (at0 ? 0 : base - 1);
-                const f4u A = *reinterpret_cast<const f4u *>(src);
-                const f4u B = *reinterpret_cast<const f4u *>(src + 4);
-                const float C = src[8];
-                float W[9] = {A[0], A[1], A[2], A[3], B[0], B[1], B[2], B[3], C};
-                float L[9];
+            const bool at0 = s == 0 && p0 + n0 == 0;
+            float W[9] = {A[s][0], A[s][1], A[s][2], A[s][3], B[s][0], B[s][1], B[s][2], B[s][3], C[s]};
+            float L[9];
 #pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    float v = at0 ? W[i ? i - 1 : 0] : W[i];
-                    if (a.scale) v *= sc;   // normalizeVolume first (src/main.cpp:82), then pre-emphasis
-                    L[i] = v;
-                }
-                if (a.preemph) {
-                    // v(p) = x[q] - alpha * x[q-1], q = max(p, 1)  (src/clip.cpp:199-205: x[0] takes the new x[1])
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const float m = a.alpha * L[e];
-                        y[s][e] = L[e + 1] - m;
-                    }
-                    if (at0) {
-                        const float m = a.alpha * L[1];
-                        y[s][0] = L[2] - m;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) y[s][e] = L[e + 1];
-                }
+            for (int i = 0; i < 9; i++) {
+                float v = (s == 0 && at0) ? W[i ? i - 1 : 0] : W[i];
+                L[i] = v * sc;   // normalizeVolume first (src/main.cpp:82; sc = 1 without a gain), then pre-emphasis
+            }
+            if (a.preemph) {
+                // v(p) = x[q] - alpha * x[q-1], q = max(p, 1)  (src/clip.cpp:199-205: x[0] takes the new x[1])
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    if (n0 + e >= a.half) y[s][e] = 0.0f;   // (the window itself is part of the table)
-                    ymax = fmaxf(ymax, fabsf(y[s][e]));
+                    const float m = a.alpha * L[e];
+                    y[s][e] = L[e + 1] - m;
+                }
+                if (s == 0 && at0) {
+                    const float m = a.alpha * L[1];
+                    y[s][0] = L[2] - m;
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; e++) y[s][e] = 0.0f;
+                for (int e = 0; e < 8; e++) y[s][e] = L[e + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (!valid || n0 + e >= a.half) y[s][e] = 0.0f;   // (the window itself is part of the table)
+                ymax = fmaxf(ymax, fabsf(y[s][e]));
             }
         }
         ymax = fmaxf(ymax, __shfl_xor(ymax, 32, 64));
