@@ -145,7 +145,8 @@ __device__ __forceinline__ float srx_logprob_exact(const float *__restrict__ fv,
 // The statistics form: the frame-independent sum (l2pi + log(var[i])) and the reciprocal of the variance come from
 // per-model tables, so the inner loop has no division and no log.  tt * (1 / var) differs from tt / var by at most one
 // ulp of the f64 quotient, 2^-29 of the f32 rounding applied to `res` on the next line (the reference divides in
-// 80-bit long double; neither f64 form reproduces that bit for bit).
+// 80-bit long double; neither f64 form reproduces that bit for bit).  The multiply and the add of the constant are
+// one fused operation (one f64 rounding instead of two, before the f32 rounding of `res`).
 __device__ __forceinline__ float srx_logprob_exact_lc(const float *__restrict__ fv, const double *__restrict__ mean,
                                                       const double *__restrict__ rvar, const double *__restrict__ lconst, float logwt,
                                                       int D) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ float srx_logprob_exact_lc(const float *__restrict__ 
     for (int i = 0; i < D; i++) {
         float t = (float)((double)fv[i] - mean[i]);
         float tt = t * t;
-        double term = lconst[i] + (double)tt * rvar[i];
+        double term = fma((double)tt, rvar[i], lconst[i]);
         res = (float)((double)res + term);
     }
     float h = -0.5f * res;

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
                                                      const double *__restrict__ lconst, const float *__restrict__ logwt,
                                                      float *__restrict__ logp, float *__restrict__ shift) {
     extern __shared__ double par[];          // mean[M][D], rvar[M][D], lconst[M][D]
-    __shared__ float xs[LP_STEP][65];        // one step's feature rows (D <= 64)
+    __shared__ double xs[LP_STEP][65];       // one step's feature rows, already widened (D <= 64)
     __shared__ int fts[2][LP_STEP];
     __shared__ float smax[16];
     const int item = blockIdx.x;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
         for (int k = 0; k < NXR; k++) {
             const int i = threadIdx.x + 256 * k;
             const int ff = i / D, d = i - ff * D;
-            if (i < LP_STEP * D) xs[ff][d] = xr[k];
+            if (i < LP_STEP * D) xs[ff][d] = (double)xr[k];
         }
         if (threadIdx.x < frames_of(st + 1)) fts[cur ^ 1][threadIdx.x] = ord;
         __syncthreads();
@@ -279,9 +279,9 @@ __global__ __launch_bounds__(256) void k_em_logp_seg(const float *__restrict__ f
                 const double mu = qm[i], rv = qr[i], lc = ql[i];
 #pragma unroll
                 for (int k = 0; k < LP_FPT; k++) {
-                    const float t = (float)((double)xs[f + 16 * k][i] - mu);
+                    const float t = (float)(xs[f + 16 * k][i] - mu);
                     const float tt = t * t;
-                    const double term = lc + (double)tt * rv;
+                    const double term = fma((double)tt, rv, lc);   // one rounding fewer than the reference's two
                     res[k] = (float)((double)res[k] + term);
                 }
             }
