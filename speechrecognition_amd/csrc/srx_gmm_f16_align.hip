@@ -249,16 +249,26 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
             stage[(f * 32 + j) * LDR + tq * SPT + hh * NST + st] = v;
         });
     };
-    // writes slab `sb` (states sb*SB ..): 64 lanes walk the [64][SB] block row-major, so a row's SB states leave as one
-    // contiguous segment of the frame-major output
+    // writes slab `sb` (states sb*SB ..): lane f owns frame row f of the [64][SB] block (row stride LDR is odd, so the
+    // 64 lanes read 64 different banks) and stores its SB states as 128-bit pieces -- 4-byte alignment is enough for
+    // global_store_dwordx4 -- into the frame-major output; the slab that holds the row's end goes element by element
     auto flush_slab = [&](int sb) __attribute__((always_inline)) {
+        typedef float f4u_ __attribute__((ext_vector_type(4), aligned(4)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 4
-        for (int e = lane; e < 64 * SB; e += 64) {
-            const int f = e / SB, c = e % SB;
-            const int lf = lf0 + f, sl = sb * SB + c;
-            const float v = stage[f * LDR + c];
-            if (lf < T && sl < S) ob[(int64_t)lf * S + sl] = v;
+        float v[SB];
+#pragma unroll
+        for (int c = 0; c < SB; c++) v[c] = stage[lane * LDR + c];
+        const int lf = lf0 + lane, c0 = sb * SB;
+        if (lf < T) {
+            float *dst = ob + (int64_t)lf * S + c0;
+            if (c0 + SB <= S) {
+#pragma unroll
+                for (int c = 0; c < SB; c += 4) *reinterpret_cast<f4u_ *>(dst + c) = (f4u_){v[c], v[c + 1], v[c + 2], v[c + 3]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < SB; c++)
+                    if (c0 + c < S) dst[c] = v[c];
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
