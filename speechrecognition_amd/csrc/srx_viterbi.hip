@@ -48,30 +48,31 @@ static constexpr int NEVER = 0x7fffffff;
 // VEC: state-major dense emissions with 16-byte aligned rows (stride_t == 1, stride_g % 4 == 0): a lane fetches four
 // consecutive frames of its state's row per load -- a quarter of the load instructions and of the cache-line lookups
 // (64 lanes read 64 different rows).  The frame loop then starts at the aligned frame at or before the utterance's first.
+static constexpr int BT_CH = 32;   // 16-frame back-pointer groups staged in LDS per backtrace chunk
+
+// One utterance with SPL states per lane.  The LDS arrays belong to the kernel (sized for the batch's widest utterance);
+// sl_alloc = 64 * that width is the row stride the back-pointer workspace was laid out with.
 template <int SPL, bool BEAM, int LAY, int PF>
-__global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
-                                                const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
-                                                const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
-                                                const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
-                                                float *__restrict__ final_logp, int32_t *__restrict__ status) {
+__device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
+                                            const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
+                                            const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
+                                            const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
+                                            float *__restrict__ final_logp, int32_t *__restrict__ status, int *dmin, int *s_ntr,
+                                            uint32_t *s_bp, const int sl_alloc) {
     // LAY: 0 = strided emission matrix, 1 = VEC (see above), 2 = compact per-utterance blocks [T][S] at ebase[u] (a
     // frame's emissions are one contiguous row; the block has fewer than 2^31 entries, so offsets are 32-bit)
     constexpr bool VEC = LAY == 1, COMPACT = LAY == 2;
-    const int u = blockIdx.x;
-    if (u >= n_utt) return;
     const int lane = threadIdx.x;
     const int64_t f0 = foff[u];
     const int T = (int)(foff[u + 1] - f0);
     const int s0 = soff[u];
     const int S = soff[u + 1] - s0;
     constexpr int SL = 64 * SPL;
-    uint32_t *bpw_base = bpws + ((size_t)(f0 >> 4) + (size_t)u) * SL;
+    uint32_t *bpw_base = bpws + ((size_t)(f0 >> 4) + (size_t)u) * sl_alloc;   // rows of this utterance's own SL inside its share
 
     // minimum number of steps from state 0 (static reachability of the left-to-right topology).  The recurrence is
     // serial in s, so it must not wait on memory: the transition counts come into LDS with one coalesced load first,
     // and the two running values stay in registers (the loop's only dependent chain is integer arithmetic).
-    __shared__ int dmin[SL + 2];
-    __shared__ int s_ntr[SL];
 #pragma unroll
     for (int q = 0; q < SPL; q++) {
         const int s = q * 64 + lane;
@@ -364,8 +365,6 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     // into LDS a chunk of BT_CH groups (16 frames each) at a time with all loads in flight together, and the walk
     // reads the next group's registers from LDS while it steps through the current one.  Lane (t + a) & 63 of `pv`
     // collects the state of frame t; 64 frames go out in one store.  A whole group is walked with compile-time shifts.
-    constexpr int BT_CH = 32;
-    __shared__ uint32_t s_bp[BT_CH * SL];
     const int ng = ((T - 1 + a) >> 4) + 1;
     // One step: the 2-bit field of frame j in the current state's word is the decrement; it is also OR-ed, in place,
     // into `dec`, from which the lanes rebuild the 16 states of the group afterwards (all scalar work per frame).
@@ -433,6 +432,33 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
         path[f0] = (int)(tk1 - tk0); path[f0 + 1] = (int)(tk2 - tk1); path[f0 + 2] = (int)(tk3 - tk2);
     }
 #endif
+}
+
+// One wavefront per utterance.  SPLMAX covers the batch's widest utterance; an utterance that fits fewer states per
+// lane takes the narrower body (half or a quarter of the vector work per frame).
+template <int SPLMAX, bool BEAM, int LAY, int PF>
+__global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
+                                                const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
+                                                const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
+                                                const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
+                                                float *__restrict__ final_logp, int32_t *__restrict__ status) {
+    constexpr int SLMAX = 64 * SPLMAX;
+    __shared__ int dmin[SLMAX + 2];
+    __shared__ int s_ntr[SLMAX];
+    __shared__ uint32_t s_bp[BT_CH * SLMAX];
+    const int u = blockIdx.x;
+    if (u >= n_utt) return;
+    const int S = soff[u + 1] - soff[u];
+    constexpr int PF1 = LAY == 1 ? SRX_VIT_PF_VEC : PF;   // the narrow bodies can afford the deep prefetch
+    if (SPLMAX >= 2 && S <= 64)
+        viterbi_utt<1, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status, dmin,
+                                       s_ntr, s_bp, SLMAX);
+    else if (SPLMAX >= 4 && S <= 128)
+        viterbi_utt<2, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status, dmin,
+                                       s_ntr, s_bp, SLMAX);
+    else
+        viterbi_utt<SPLMAX, BEAM, LAY, PF>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
+                                           dmin, s_ntr, s_bp, SLMAX);
 }
 
 // ------------------------------------------------------------------------------------------
