@@ -64,6 +64,45 @@ def test_viterbi_bit_exact(ctx, oracle, words, spl):
     _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major="aligned")     # four frames per load
 
 
+def test_viterbi_mixed_widths_in_one_batch(ctx, oracle):
+    """Utterances with at most 64, at most 128 and more than 128 states in one batch: the kernel is built for the
+    widest and each utterance takes the body of its own width (one, two or four states per lane); every emission
+    layout, with and without a beam, and the compact per-utterance layout of srx_viterbi_align_dev."""
+    rng = np.random.default_rng(77)
+    G = 60
+    parts = [_make_batch(rng, 6, G, 40, 300, max_states=64 * spl, words=w) for w, spl in ((3, 1), (20, 2), (34, 4), (5, 1))]
+    ntrs = [x for p in parts for x in p[1]]
+    trs = [x for p in parts for x in p[2]]
+    tieds = [x for p in parts for x in p[3]]
+    Ts = np.concatenate([np.diff(p[4]) for p in parts])
+    order = rng.permutation(len(ntrs))
+    ntrs, trs, tieds, Ts = [ntrs[i] for i in order], [trs[i] for i in order], [tieds[i] for i in order], Ts[order]
+    widths = [len(n) for n in ntrs]
+    assert min(widths) <= 64 and any(64 < w <= 128 for w in widths) and max(widths) > 128
+    fo = np.zeros(len(ntrs) + 1, np.int64)
+    fo[1:] = np.cumsum(Ts)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 20).astype(np.float32)
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis)
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major="aligned")
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam=80.0, state_major="aligned")
+    # compact layout: utterance u owns [T_u][S_u] at emis_off[u]
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    hb.align_plan()
+    comp = np.empty(hb.emis_count, np.float32)
+    for u in range(len(ntrs)):
+        comp[hb.emis_off[u]:hb.emis_off[u + 1]] = emis[fo[u]:fo[u + 1]][:, tieds[u]].ravel()
+    path_d, final_d, status_d = hb.viterbi_align(ctx.array(comp))
+    ctx.sync()
+    path, final, status = path_d.get(), final_d.get(), status_d.get()
+    for u in range(len(ntrs)):
+        r = oracle.viterbi(emis[fo[u]:fo[u + 1]], tieds[u], ntrs[u], trs[u], 1e10, 0)
+        assert status[u] == r["status"], u
+        if r["status"] == 0:
+            assert final[u].tobytes() == r["final"].tobytes(), u
+            assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"]), u
+    hb.close()
+
+
 def test_viterbi_positive_scores_and_short_T(ctx, oracle):
     """Log-densities are routinely positive (log(2/pi) constant, src/gmm.cpp:43); T barely reaching the
     last state, T too short (NO PATH, src/hmm.cpp:212-215), T = 1."""
