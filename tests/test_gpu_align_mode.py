@@ -119,3 +119,21 @@ def test_viterbi_on_compact_emissions_matches_dense(ctx, oracle):
         assert np.array_equal(p1.get()[fo[u]:fo[u + 1]], r["path"])
     hb.close()
     model.close()
+
+
+def test_plan_rejects_a_block_beyond_32_bit_offsets(ctx):
+    """The alignment kernel indexes inside an utterance's [T_u][S_u] block with 32 bits; a block of 2^31 entries or more
+    is refused at plan creation with a message, not truncated (offsets only: nothing of that size is allocated)."""
+    from speechrecognition_amd._capi import SrxError
+    ph = np.zeros(40, np.int32)
+    ntr, tr, _ = host.build_training_hmm(ph)
+    fo = np.array([0, 1 << 26], np.int64)                 # 2^26 frames x 40 states = 2.7e9 entries
+    hb = host.HmmBatch(ctx, fo, [ntr], [tr], [np.zeros(len(ph), np.int32)])
+    with pytest.raises(SrxError) as ei:
+        hb.align_plan()
+    assert "frames" in str(ei.value) and "states" in str(ei.value)
+    fo_ok = np.array([0, 1 << 20], np.int64)
+    hb2 = host.HmmBatch(ctx, fo_ok, [ntr], [tr], [np.zeros(len(ph), np.int32)])
+    hb2.align_plan()
+    assert hb2.emis_count == (1 << 20) * len(ph)
+    hb2.close()
