@@ -256,11 +256,23 @@ __global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restric
     const int j = lane & 31, h = lane >> 5;
     const int slice = blockIdx.x % NSLICE;
     const int64_t fb = blockIdx.x / NSLICE;
-    const int tile_lo = slice * tps;
-    // tps is a multiple of U, and a slice ends on a multiple of U: its last step may run up to U-1 tiles past ntiles; those
-    // are padding in A' (states >= G, never stored).
+    // A slice holds whole unrolled steps (U tiles); the last step of the model may run up to U-1 tiles past ntiles: those
+    // are padding in A' (states >= G, never stored).  The steps are dealt out evenly, and the slices that carry one step
+    // more rotate with the frame block: a fixed split (7 x 128 + 104 tiles at G = 2,000) left one XCD idle for the last
+    // fifth of every round, while this one shifts a slice's range by at most `extra` steps, so it stays in its XCD's L2.
+    (void)tps;
     const int ntiles_r = (ntiles + U - 1) / U * U;
-    const int tile_hi = tile_lo + tps < ntiles_r ? tile_lo + tps : ntiles_r;
+    const int units = ntiles_r / U, base = units / NSLICE, extra = units % NSLICE;
+    int lo_u = slice * base, sz_u = base;
+    const int rot = (int)(fb % NSLICE);
+#pragma unroll
+    for (int s2 = 0; s2 < NSLICE; s2++) {
+        const int ex = ((s2 + rot) % NSLICE) < extra ? 1 : 0;
+        if (s2 < slice) lo_u += ex;
+        if (s2 == slice) sz_u += ex;
+    }
+    const int tile_lo = lo_u * U;
+    const int tile_hi = tile_lo + sz_u * U;
     if (tile_lo >= tile_hi) return;
     const int nchunks = (tile_hi - tile_lo + NT - 1) / NT;
     // LDS addressing by integer byte offset through an address-space-3 pointer.  (Reads through a pointer the compiler
