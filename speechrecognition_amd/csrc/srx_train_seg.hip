@@ -14,7 +14,6 @@
 
 static constexpr int CH = 2048;     // frames per work item
 static constexpr int FB = 32;       // frames staged per step
-static constexpr int ACC_MAX = 4;   // accumulators per thread (256 threads): M*(1+D) <= 1024
 
 struct EmSortView {
     int32_t *keys_in, *keys_out, *vals_in, *order;   // [T] each; order = frame indices sorted by state
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(256) void k_em_seg_reduce(const int32_t *__restrict
     }
 }
 
-bool srx_em_seg_applicable(int M, int D) { return M <= 16 && D <= 63; }   // 16 x 64 sums in 256 threads x ACC_MAX
+bool srx_em_seg_applicable(int M, int D) { return M <= 16 && D <= 63; }   // 16 components x 64 row elements: 256 threads x at most 4 sums
 
 // Sorts the frames of alignment `gid` by state into workspace slot 2 (kept until the next sort).
 int srx_em_seg_sort(srx_ctx *ctx, const int32_t *gid, int64_t T, int G) {
