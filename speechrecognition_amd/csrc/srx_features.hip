@@ -37,15 +37,24 @@ __global__ __launch_bounds__(256) void k_features(const float *__restrict__ raw,
     int64_t *ub = reinterpret_cast<int64_t *>(dl + (FBK + 2) * nc);   // [FBK + 4] utterance base of frame F0 - 2 + r
     int64_t *un = ub + (FBK + 4);                                      // [FBK + 4] its length (0: no such frame)
     const int64_t F0 = (int64_t)blockIdx.x * FBK;
+    // one binary search per block (a chain of dependent loads; uniform, so scalar loads), on the block's first frame;
+    // a row walks forward from that utterance
+    int u0;
+    {
+        const int64_t f0 = F0 - 2 < 0 ? 0 : F0 - 2;
+        int lo = 0, hi = n_utt;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (foff[mid] <= f0) lo = mid; else hi = mid;
+        }
+        u0 = lo;
+    }
     for (int r = threadIdx.x; r < FBK + 4; r += 256) {
         const int64_t f = F0 - 2 + r;
         int64_t base = 0, n = 0;
         if (f >= 0 && f < total_frames) {
-            int lo = 0, hi = n_utt;
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (foff[mid] <= f) lo = mid; else hi = mid;
-            }
+            int lo = u0;
+            while (lo + 1 < n_utt && foff[lo + 1] <= f) lo++;
             base = foff[lo];
             n = foff[lo + 1] - base;
         }

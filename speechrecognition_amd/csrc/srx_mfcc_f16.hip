@@ -171,7 +171,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mfcc_f16(Mfcc16Args a) {
     int64_t p0 = 0;
     float sc = 1.0f;
     if (valid) {
-        const int u = find_utt16(a.foff, a.n_utt, f);
+        // the binary search is a chain of dependent loads: it runs once per wave, on the wave's first frame (uniform, so
+        // the loads are scalar ones), and a lane walks forward from there (its frame is at most 31 further on)
+        const int64_t fw = (int64_t)blockIdx.x * FRAMES_WG + 32 * w;
+        int u = find_utt16(a.foff, a.n_utt, fw < a.total_frames ? fw : a.total_frames - 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        while (u + 1 < a.n_utt && a.foff[u + 1] <= f) u++;
         xu = a.x + a.soff[u];
         p0 = (f - a.foff[u]) * (int64_t)a.hop;
         if (a.scale) sc = a.scale[u];
