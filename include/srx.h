@@ -203,11 +203,14 @@ typedef struct {
  * emis[t*stride_t + tied[s]*stride_g] = (*acm)(*fvs[t], states[s].ctx), t counted over the whole
  * batch (the strides of srx_gmm_score_dev).  Outputs: path[total_frames]
  * (state index within the utterance), final_logp[n_utt] (= curr[best]), status[n_utt]
- * (0 ok, 1 "NO PATH": path/final untouched).  prevp of the reference = final_logp / T.
+ * (0 ok, 1 "NO PATH": path/final untouched; 2: the utterance has more states than hmm->max_states, nothing computed).
+ * prevp of the reference = final_logp / T.
  * Score is bit-exact w.r.t. the reference's f32 add order (it accumulates logp across a source's
  * transitions, src/hmm.cpp:164-169); exact ties are resolved towards the higher source index
  * (the reference's order is unordered_map iteration order, i.e. unspecified).
- * beam_width >= 1e10 (the reference default, src/hmm.cpp:150) disables the beam test.
+ * beam_width >= 1e10 is the reference default (src/hmm.cpp:150).  The reference still applies its pruning test there
+ * (src/hmm.cpp:165: a source at -inf, or 1e10 below the frame's best, is skipped; if every candidate of a frame dies the
+ * result is NO PATH): the kernel runs without the test and repeats an utterance with it when some score left +-2.5e9.
  * Fastest layout: state-major with 16-byte aligned rows (stride_t == 1, stride_g a multiple of 4, emis_dev 16-byte
  * aligned): four frames per load. */
 int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,

@@ -152,6 +152,20 @@ def gmm_score(feats, mean, var, logwt, D, mode=0):
     return out
 
 
+def gmm_score_shifted(feats, mean, var, logwt, D):
+    """log sum_m exp(g_m) taken relative to the largest component: the oracle's per-component log-densities (mode 0 on
+    the [G*M, 1, D] view of the model) combined in f64 numpy.  Equal to gmm_score(..., mode=1) wherever that is finite;
+    finite where mode 1 underflows to -inf.  This is what the library returns there (parity unpinned: gmm.cpp:103-107 is
+    dead code in the reference, and -inf is what it would give)."""
+    mean = np.asarray(mean)
+    G, M, _ = mean.shape
+    comp = gmm_score(feats, mean.reshape(G * M, 1, D), np.asarray(var).reshape(G * M, 1, D),
+                     np.asarray(logwt, np.float32).reshape(G * M, 1), D, 0).astype(np.float64).reshape(-1, G, M)
+    mx = comp.max(axis=2, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        return (np.log(np.exp(comp - mx).sum(axis=2)) + mx[:, :, 0]).astype(np.float32)
+
+
 # ---------------------------------------------------------------- HMM
 def build_training_hmm(phones):
     phones = np.ascontiguousarray(phones, dtype=np.int32)
@@ -186,6 +200,17 @@ def train_transitions(path, ntr, trlogp):
     path = np.ascontiguousarray(path, dtype=np.int32)
     lib().orc_train_transitions(path, len(path), np.ascontiguousarray(ntr, dtype=np.int32), trlogp)
     return trlogp
+
+
+def state_model(cls, adv, C_):
+    """state_model::augment over the frames of the final paths (src/hmm.cpp:46-51, 350-356): cls[t] = tied class of
+    the path state at frame t, adv[t] = its get_adv_prob().  Returns (probsum f32 [C], count i32 [C])."""
+    cls = np.ascontiguousarray(cls, dtype=np.int32)
+    adv = np.ascontiguousarray(adv, dtype=np.float32)
+    ps = np.zeros(C_, np.float32)
+    cnt = np.zeros(C_, np.int32)
+    lib().orc_state_model(cls, adv, len(cls), C_, ps, cnt)
+    return ps, cnt
 
 
 def em_statistics(feats, gid, D, A_mean, A_var, A_weight, blend_keep=0.2):

@@ -11,6 +11,8 @@
 
 #include "../../include/srx.h"
 
+static constexpr int SRX_MAX_DEVICES = 64;   // srx_ctx_create rejects a device index beyond this
+
 struct srx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -77,6 +79,16 @@ static inline int srx_fail(srx_ctx *ctx, int code, const char *fmt, ...) {
         if (!(cond)) return srx_fail((ctx), SRX_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// First line of every entry point that takes a context: rejects a null context and makes the context's device the
+// calling thread's current one, so that allocations, function attributes and launches land on that GPU whatever the
+// caller's current device is (a process may hold contexts on several devices; each context is still used by one thread
+// at a time).
+#define SRX_ENTER(ctx, name)                                                                                 \
+    do {                                                                                                     \
+        if (!(ctx)) return srx_fail(nullptr, SRX_ERR_INVALID, "%s: null ctx", name);                         \
+        SRX_HIP(ctx, hipSetDevice((ctx)->device));                                                           \
+    } while (0)
+
 #define SRX_LAUNCH_CHECK(ctx) SRX_HIP(ctx, hipGetLastError())
 
 // RAII device buffer for the host-pointer convenience entry points.
@@ -140,6 +152,32 @@ __device__ __forceinline__ float srx_logprob_exact(const float *__restrict__ fv,
     }
     float h = -0.5f * res;
     return h + logwt;
+}
+
+// gmm::operator() as the commented-out intent of src/gmm.cpp:103-107: log(sum_m exp(g_m)) in double, for the M components
+// of one tied state (mean/var/logwt point at its component 0).  Written as the reference has it wherever that form is
+// well inside the f64 range; where every exp() underflows (a frame tens of standard deviations from every mean: the
+// reference's form gives log(0) = -inf there, and one such frame removes its whole utterance from training through the
+// pruning test of src/hmm.cpp:165) or overflows, the sum is taken relative to the largest component, which is the same
+// quantity without the range limit.  DESIGN.md section 2 lists this as a divergence from the dead code.
+__device__ __forceinline__ float srx_lse_exact(const float *__restrict__ fv, const double *__restrict__ mean,
+                                               const double *__restrict__ var, const float *__restrict__ logwt, int M, int D) {
+    double s = 0.0;
+    float mxv = -__builtin_huge_valf();
+    for (int m = 0; m < M; m++) {
+        const float lp = srx_logprob_exact(fv, mean + (size_t)m * D, var + (size_t)m * D, logwt[m], D);
+        s += exp((double)lp);
+        mxv = fmaxf(mxv, lp);
+    }
+    if (s > 1e-290 && s < 1e290) return (float)log(s);
+    if (s != s) return (float)s;                            // NaN feature or parameter: NaN, as log(NaN) in the reference's form
+    if (mxv == -__builtin_huge_valf()) return mxv;          // every component at -inf (all weights zero)
+    double s2 = 0.0;
+    for (int m = 0; m < M; m++) {
+        const float lp = srx_logprob_exact(fv, mean + (size_t)m * D, var + (size_t)m * D, logwt[m], D);
+        s2 += exp((double)lp - (double)mxv);
+    }
+    return (float)(log(s2) + (double)mxv);
 }
 
 // The statistics form: the frame-independent sum (l2pi + log(var[i])) and the reciprocal of the variance come from

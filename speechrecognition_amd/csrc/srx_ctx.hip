@@ -15,7 +15,7 @@ extern "C" int srx_ctx_create(int device, void *stream, srx_ctx **out) {
     if (e != hipSuccess || n <= 0)
         return srx_fail(nullptr, SRX_ERR_DEVICE, "srx_ctx_create: no HIP device (%s); libsrx has no CPU fallback",
                         hipGetErrorString(e));
-    if (device < 0 || device >= n) return srx_fail(nullptr, SRX_ERR_INVALID, "srx_ctx_create: device %d of %d", device, n);
+    if (device < 0 || device >= n || device >= SRX_MAX_DEVICES) return srx_fail(nullptr, SRX_ERR_INVALID, "srx_ctx_create: device %d of %d", device, n);
     SRX_HIP(nullptr, hipSetDevice(device));
     hipDeviceProp_t prop;
     SRX_HIP(nullptr, hipGetDeviceProperties(&prop, device));
@@ -51,7 +51,7 @@ extern "C" void srx_ctx_destroy(srx_ctx *ctx) {
 }
 
 extern "C" int srx_profile_enable(srx_ctx *ctx, int on) {
-    SRX_REQUIRE(nullptr, ctx, "srx_profile_enable: null ctx");
+    SRX_ENTER(ctx, "srx_profile_enable");
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     ctx->prof.clear();
@@ -60,7 +60,7 @@ extern "C" int srx_profile_enable(srx_ctx *ctx, int on) {
 }
 
 extern "C" int srx_profile_query(srx_ctx *ctx, const char *kernel, double *total_ms, int64_t *launches) {
-    SRX_REQUIRE(nullptr, ctx, "srx_profile_query: null ctx");
+    SRX_ENTER(ctx, "srx_profile_query");
     SRX_REQUIRE(ctx, kernel && total_ms && launches, "srx_profile_query: null argument");
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double ms = 0.0;
@@ -94,7 +94,7 @@ int srx_workspace(srx_ctx *ctx, int slot, size_t bytes, void **out) {
 extern "C" const char *srx_last_error(const srx_ctx *ctx) { return ctx ? ctx->err : g_srx_create_err; }
 
 extern "C" int srx_sync(srx_ctx *ctx) {
-    SRX_REQUIRE(nullptr, ctx, "srx_sync: null ctx");
+    SRX_ENTER(ctx, "srx_sync");
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SRX_OK;
 }
@@ -106,28 +106,28 @@ extern "C" int srx_malloc(srx_ctx *ctx, size_t bytes, void **dev) {
     return SRX_OK;
 }
 extern "C" int srx_free(srx_ctx *ctx, void *dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_free: null ctx");
+    SRX_ENTER(ctx, "srx_free");
     if (!dev) return SRX_OK;
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SRX_HIP(ctx, hipFree(dev));
     return SRX_OK;
 }
 extern "C" int srx_memcpy_h2d(srx_ctx *ctx, void *dev, const void *host, size_t bytes) {
-    SRX_REQUIRE(nullptr, ctx, "srx_memcpy_h2d: null ctx");
+    SRX_ENTER(ctx, "srx_memcpy_h2d");
     if (!bytes) return SRX_OK;
     SRX_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SRX_OK;
 }
 extern "C" int srx_memcpy_d2h(srx_ctx *ctx, void *host, const void *dev, size_t bytes) {
-    SRX_REQUIRE(nullptr, ctx, "srx_memcpy_d2h: null ctx");
+    SRX_ENTER(ctx, "srx_memcpy_d2h");
     if (!bytes) return SRX_OK;
     SRX_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SRX_OK;
 }
 extern "C" int srx_memset(srx_ctx *ctx, void *dev, int value, size_t bytes) {
-    SRX_REQUIRE(nullptr, ctx, "srx_memset: null ctx");
+    SRX_ENTER(ctx, "srx_memset");
     if (!bytes) return SRX_OK;
     SRX_HIP(ctx, hipMemsetAsync(dev, value, bytes, ctx->stream));
     return SRX_OK;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_features(const float *__restrict__ raw,
 
 extern "C" int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const float *ceps_dev, const int64_t *frame_off_dev,
                                       int n_utt, int64_t total_frames, float *feats_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_features_batch_dev: null ctx");
+    SRX_ENTER(ctx, "srx_features_batch_dev");
     SRX_REQUIRE(ctx, ceps_dev && frame_off_dev && feats_dev, "srx_features_batch_dev: null argument");
     SRX_REQUIRE(ctx, WL >= 0 && WL <= 64 && n_ceps >= 1 && n_utt >= 0 && total_frames >= 0, "srx_features_batch_dev: bad size");
     if (n_utt == 0 || total_frames == 0) return SRX_OK;
@@ -123,7 +123,7 @@ extern "C" int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const fl
 
 extern "C" int srx_features_batch(srx_ctx *ctx, int WL, int n_ceps, const float *ceps, const int64_t *frame_off, int n_utt,
                                   float *feats) {
-    SRX_REQUIRE(nullptr, ctx, "srx_features_batch: null ctx");
+    SRX_ENTER(ctx, "srx_features_batch");
     SRX_REQUIRE(ctx, ceps && frame_off && feats && n_utt >= 0 && n_ceps >= 1, "srx_features_batch: bad argument");
     if (n_utt == 0) return SRX_OK;
     const int64_t nf = frame_off[n_utt];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ feats,
 
 extern "C" int srx_corpus_mean_var_dev(srx_ctx *ctx, const float *feats_dev, int ld, int64_t total_frames, int D,
                                        double *sum_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_corpus_mean_var_dev: null ctx");
+    SRX_ENTER(ctx, "srx_corpus_mean_var_dev");
     SRX_REQUIRE(ctx, feats_dev && sum_dev && D >= 1 && ld >= D && total_frames >= 1, "srx_corpus_mean_var_dev: bad argument");
     SRX_HIP(ctx, hipMemsetAsync(sum_dev, 0, 2 * D * sizeof(double), ctx->stream));
     int nb = (int)(ceil_div64(total_frames, 256) < 1024 ? ceil_div64(total_frames, 256) : 1024);

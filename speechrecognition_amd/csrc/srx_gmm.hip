@@ -21,7 +21,7 @@
 // model bookkeeping
 // ------------------------------------------------------------------------------------------
 extern "C" int srx_model_create(srx_ctx *ctx, int G, int M, int D, srx_model **out) {
-    SRX_REQUIRE(nullptr, ctx, "srx_model_create: null ctx");
+    SRX_ENTER(ctx, "srx_model_create");
     SRX_REQUIRE(ctx, out && G >= 1 && M >= 1 && D >= 1 && D <= 128, "srx_model_create: bad shape G=%d M=%d D=%d", G, M, D);
     srx_model *m = new srx_model();
     m->ctx = ctx;
@@ -59,6 +59,7 @@ extern "C" void srx_model_destroy(srx_model *m) {
 extern "C" int srx_model_set(srx_model *m, const double *mean, const double *var, const float *weight) {
     SRX_REQUIRE(nullptr, m, "srx_model_set: null model");
     srx_ctx *ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
     SRX_REQUIRE(ctx, mean && var && weight, "srx_model_set: null argument");
     const size_t n = (size_t)m->G * m->M;
     SRX_HIP(ctx, hipMemcpyAsync(m->mean, mean, n * m->D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -76,6 +77,7 @@ extern "C" int srx_model_set(srx_model *m, const double *mean, const double *var
 extern "C" int srx_model_get(srx_model *m, double *mean, double *var, float *weight) {
     SRX_REQUIRE(nullptr, m, "srx_model_get: null model");
     srx_ctx *ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)m->G * m->M;
     if (mean) SRX_HIP(ctx, hipMemcpyAsync(mean, m->mean, n * m->D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (var) SRX_HIP(ctx, hipMemcpyAsync(var, m->var, n * m->D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -87,6 +89,7 @@ extern "C" int srx_model_get(srx_model *m, double *mean, double *var, float *wei
 extern "C" int srx_model_copy(srx_model *dst, const srx_model *src) {
     SRX_REQUIRE(nullptr, dst && src, "srx_model_copy: null model");
     srx_ctx *ctx = dst->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
     SRX_REQUIRE(ctx, dst->G == src->G && dst->M == src->M && dst->D == src->D, "srx_model_copy: shape mismatch");
     const size_t n = (size_t)dst->G * dst->M;
     SRX_HIP(ctx, hipMemcpyAsync(dst->mean, src->mean, n * dst->D * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -114,12 +117,8 @@ __global__ __launch_bounds__(256) void k_gmm_exact(const float *__restrict__ fea
         const size_t o = (size_t)g * M;
         r = srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D);
     } else {
-        double s = 0.0;
-        for (int m = 0; m < M; m++) {
-            const size_t o = (size_t)g * M + m;
-            s += exp((double)srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D));
-        }
-        r = (float)log(s);
+        const size_t o = (size_t)g * M;
+        r = srx_lse_exact(fv, mean + o * D, var + o * D, logwt + o, M, D);
     }
     out[t * st_t + (int64_t)g * st_g] = r;
 }
@@ -132,7 +131,7 @@ int srx_gmm_score_mfma(srx_ctx *ctx, srx_model *m, int mix_mode, const float *fe
 
 extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
                                  int64_t T, float *out_dev, int64_t stride_t, int64_t stride_g) {
-    SRX_REQUIRE(nullptr, ctx, "srx_gmm_score_dev: null ctx");
+    SRX_ENTER(ctx, "srx_gmm_score_dev");
     SRX_REQUIRE(ctx, m && feats_dev && out_dev, "srx_gmm_score_dev: null argument");
     SRX_REQUIRE(ctx, ld >= m->D && T >= 0, "srx_gmm_score_dev: ld=%d < D=%d", ld, m->D);
     SRX_REQUIRE(ctx, (stride_g == 1 && stride_t >= m->G) || (stride_t == 1 && stride_g >= T),
@@ -158,7 +157,7 @@ extern "C" int srx_gmm_score_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int s
 
 extern "C" int srx_gmm_score(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats, int ld, int64_t T,
                              float *out) {
-    SRX_REQUIRE(nullptr, ctx, "srx_gmm_score: null ctx");
+    SRX_ENTER(ctx, "srx_gmm_score");
     SRX_REQUIRE(ctx, m && feats && out && T >= 0, "srx_gmm_score: bad argument");
     if (T == 0) return SRX_OK;
     DevBuf df, dout;

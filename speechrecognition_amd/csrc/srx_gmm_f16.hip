@@ -204,12 +204,8 @@ __global__ __launch_bounds__(256) void k_gmm_fixup16(const unsigned char *__rest
                 const size_t o = (size_t)g * M;
                 r = srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D);
             } else {
-                double s = 0.0;
-                for (int m = 0; m < M; m++) {
-                    const size_t o = (size_t)g * M + m;
-                    s += exp((double)srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D));
-                }
-                r = (float)log(s);
+                const size_t o = (size_t)g * M;
+                r = srx_lse_exact(fv, mean + o * D, var + o * D, logwt + o, M, D);
             }
             out[t * st_t + (int64_t)g * st_g] = r;
         }
@@ -444,11 +440,11 @@ static int launch_f16(srx_ctx *ctx, srx_model *m, const f16x8 *Bp, int64_t T, in
     typedef F16Cfg<MP> Cfg;
     const size_t lds_bytes = (size_t)2 * Cfg::NT * 2 * KS * 1024 + (size_t)NW16 * Cfg::STAGE_FLOATS * sizeof(float);
     SRX_REQUIRE(ctx, lds_bytes <= 160 * 1024, "srx_gmm_score: LDS budget exceeded (%zu bytes)", lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[SRX_MAX_DEVICES] = {};   // the attribute is per device
+    if (!attr_set[ctx->device]) {
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_f16<MP, KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_f16<MP, KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[ctx->device] = true;
     }
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;

@@ -24,7 +24,7 @@ struct srx_align_plan {
 };
 
 extern "C" int srx_align_plan_create(srx_ctx *ctx, const int64_t *frame_off, const int32_t *state_off, int n_utt, srx_align_plan **out) {
-    SRX_REQUIRE(nullptr, ctx, "srx_align_plan_create: null ctx");
+    SRX_ENTER(ctx, "srx_align_plan_create");
     SRX_REQUIRE(ctx, frame_off && state_off && out && n_utt >= 0, "srx_align_plan_create: bad argument");
     srx_align_plan *p = new srx_align_plan();
     p->ctx = ctx;
@@ -76,6 +76,8 @@ extern "C" int srx_align_plan_emission_offsets(const srx_align_plan *p, int64_t 
     std::memcpy(off, p->emis_off_host.data(), p->emis_off_host.size() * 8);
     return SRX_OK;
 }
+
+int srx_align_plan_n_utt(const srx_align_plan *p) { return p ? p->n_utt : -1; }
 
 extern "C" const int64_t *srx_align_plan_emission_offsets_dev(const srx_align_plan *p) { return p ? p->emis_off : nullptr; }
 
@@ -162,12 +164,8 @@ __global__ __launch_bounds__(256) void k_gmm_exact_align(const unsigned char *__
                 const size_t o = (size_t)g * M;
                 r = srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D);
             } else {
-                double acc = 0.0;
-                for (int m = 0; m < M; m++) {
-                    const size_t o = (size_t)g * M + m;
-                    acc += exp((double)srx_logprob_exact(fv, mean + o * D, var + o * D, logwt[o], D));
-                }
-                r = (float)log(acc);
+                const size_t o = (size_t)g * M;
+                r = srx_lse_exact(fv, mean + o * D, var + o * D, logwt + o, M, D);
             }
             ob[(int64_t)lf * S + s] = r;
         }
@@ -347,7 +345,7 @@ static int launch_exact_align(srx_ctx *ctx, srx_model *m, int mix_mode, const sr
 
 extern "C" int srx_gmm_score_align_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
                                        const srx_hmm_batch *hmm, const srx_align_plan *plan, float *emis_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_gmm_score_align_dev: null ctx");
+    SRX_ENTER(ctx, "srx_gmm_score_align_dev");
     SRX_REQUIRE(ctx, m && feats_dev && hmm && plan && emis_dev, "srx_gmm_score_align_dev: null argument");
     SRX_REQUIRE(ctx, mix_mode == SRX_MIX_COMPONENT0 || mix_mode == SRX_MIX_LOGSUMEXP, "srx_gmm_score_align_dev: unknown mix mode %d", mix_mode);
     SRX_REQUIRE(ctx, score_path == SRX_SCORE_MFMA_F16X3 || score_path == SRX_SCORE_EXACT,

@@ -342,10 +342,10 @@ static int launch_mfma(srx_ctx *ctx, srx_model *m, const float *Xc, int64_t T, i
     const int slab = ndma * 256;  // floats; the last DMA piece may overrun the tile, never the slab
     const size_t lds_bytes = ((size_t)RT * KSP * 64 + (size_t)NW * 2 * slab + 64) * sizeof(float);
     SRX_REQUIRE(ctx, lds_bytes <= 160 * 1024, "srx_gmm_score: D=%d needs %zu bytes of LDS (max 160 KiB)", m->D, lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[SRX_MAX_DEVICES] = {};   // the attribute is per device
+    if (!attr_set[ctx->device]) {
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_gmm_mfma<MP, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[ctx->device] = true;
     }
     const int spt = 32 / MP;
     const int ntiles = (m->G + spt - 1) / spt;

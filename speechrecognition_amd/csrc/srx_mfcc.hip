@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_mfcc_tile(MfccArgs a) {
 // ------------------------------------------------------------------------------------------
 extern "C" int srx_mfcc_plan_create(srx_ctx *ctx, const srx_mfcc_cfg *cfg, const srx_filter *fb, int n_filters,
                                     srx_mfcc_plan **out) {
-    SRX_REQUIRE(nullptr, ctx, "srx_mfcc_plan_create: null ctx");
+    SRX_ENTER(ctx, "srx_mfcc_plan_create");
     SRX_REQUIRE(ctx, cfg && fb && out, "srx_mfcc_plan_create: null argument");
     SRX_REQUIRE(ctx, cfg->window_len >= 8 && cfg->frame_shift >= 1, "srx_mfcc_plan_create: bad window/shift");
     SRX_REQUIRE(ctx, cfg->n_ceps >= 1 && cfg->n_ceps <= 16, "srx_mfcc_plan_create: n_ceps must be 1..16");
@@ -385,7 +385,7 @@ static int round_ld(int n) {  // smallest 2*odd >= n
 extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev,
                                   const int64_t *sample_off_dev, int n_utt, const int64_t *frame_off_dev,
                                   int64_t total_frames, float *scratch_scale_dev, float *ceps_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_mfcc_batch_dev: null ctx");
+    SRX_ENTER(ctx, "srx_mfcc_batch_dev");
     SRX_REQUIRE(ctx, plan && samples_dev && sample_off_dev && frame_off_dev && ceps_dev, "srx_mfcc_batch_dev: null argument");
     SRX_REQUIRE(ctx, n_utt >= 0 && total_frames >= 0, "srx_mfcc_batch_dev: negative size");
     if (n_utt == 0 || total_frames == 0) return SRX_OK;
@@ -414,10 +414,10 @@ extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const
     const int ldmax = a.ldA > a.ldM ? a.ldA : a.ldM;
     const size_t lds_bytes = ((size_t)TILE_F * ldmax + (size_t)KC * LDW) * sizeof(float);
     SRX_REQUIRE(ctx, lds_bytes <= 160 * 1024, "srx_mfcc_batch_dev: LDS need %zu exceeds 160 KiB", lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[SRX_MAX_DEVICES] = {};   // the attribute is per device
+    if (!attr_set[ctx->device]) {
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_mfcc_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[ctx->device] = true;
     }
     const int64_t nblk = ceil_div64(total_frames, TILE_F);
     SRX_REQUIRE(ctx, nblk < (1ll << 31), "srx_mfcc_batch_dev: too many frames");
@@ -431,7 +431,7 @@ extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const
 
 extern "C" int srx_mfcc_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples, const int64_t *sample_off,
                               int n_utt, float *ceps, int64_t *frame_off) {
-    SRX_REQUIRE(nullptr, ctx, "srx_mfcc_batch: null ctx");
+    SRX_ENTER(ctx, "srx_mfcc_batch");
     SRX_REQUIRE(ctx, plan && samples && sample_off && ceps && frame_off && n_utt >= 0, "srx_mfcc_batch: bad argument");
     int rc = srx_mfcc_frame_offsets(&plan->cfg, sample_off, n_utt, frame_off);
     if (rc != SRX_OK) return srx_fail(ctx, rc, "%s", srx_last_error(nullptr));
@@ -457,7 +457,7 @@ extern "C" int srx_mfcc_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const flo
 
 extern "C" int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt,
                                         float target_rms, float *scratch_scale_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_normalize_volume_dev: null ctx");
+    SRX_ENTER(ctx, "srx_normalize_volume_dev");
     SRX_REQUIRE(ctx, samples_dev && sample_off_dev && scratch_scale_dev && n_utt >= 0, "srx_normalize_volume_dev: bad argument");
     if (n_utt == 0) return SRX_OK;
     {
@@ -475,7 +475,7 @@ extern "C" int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const 
 }
 
 extern "C" int srx_scale_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt, const float *scale_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_scale_dev: null ctx");
+    SRX_ENTER(ctx, "srx_scale_dev");
     SRX_REQUIRE(ctx, samples_dev && sample_off_dev && scale_dev && n_utt >= 0, "srx_scale_dev: bad argument");
     if (n_utt == 0) return SRX_OK;
     {
@@ -488,7 +488,7 @@ extern "C" int srx_scale_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sa
 
 extern "C" int srx_rms_amplitude_dev(srx_ctx *ctx, const float *samples_dev, const int64_t *sample_off_dev, int n_utt,
                                      double *rms_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_rms_amplitude_dev: null ctx");
+    SRX_ENTER(ctx, "srx_rms_amplitude_dev");
     SRX_REQUIRE(ctx, samples_dev && sample_off_dev && rms_dev && n_utt >= 0, "srx_rms_amplitude_dev: bad argument");
     if (n_utt == 0) return SRX_OK;
     {
@@ -501,7 +501,7 @@ extern "C" int srx_rms_amplitude_dev(srx_ctx *ctx, const float *samples_dev, con
 
 extern "C" int srx_preemphasis_dev(srx_ctx *ctx, float *samples_dev, float *scratch_dev, const int64_t *sample_off_dev,
                                    int n_utt, int64_t total_samples, float alpha) {
-    SRX_REQUIRE(nullptr, ctx, "srx_preemphasis_dev: null ctx");
+    SRX_ENTER(ctx, "srx_preemphasis_dev");
     SRX_REQUIRE(ctx, samples_dev && scratch_dev && sample_off_dev && n_utt >= 0 && total_samples >= 0,
                 "srx_preemphasis_dev: bad argument");
     if (n_utt == 0 || total_samples == 0) return SRX_OK;

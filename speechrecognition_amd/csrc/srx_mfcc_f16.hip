@@ -354,11 +354,11 @@ int srx_mfcc16_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samp
     const size_t lds_bytes = (size_t)2 * (KS * 4 + NRT * 4) * 1024;
     const int64_t nblk = ceil_div64(total_frames, FRAMES_WG);
     SRX_REQUIRE(ctx, nblk < (1ll << 31), "srx_mfcc_batch_dev: too many frames");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[SRX_MAX_DEVICES] = {};   // the attribute is per device
+    if (!attr_set[ctx->device]) {
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_mfcc_f16<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_mfcc_f16<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[ctx->device] = true;
     }
     {
         SrxProf prof_(ctx, "k_mfcc_f16");

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_state_model(int n_utt, const int64_t *_
 
 extern "C" int srx_state_model_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *cls_dev, const int32_t *path_dev,
                                    const int32_t *status_dev, int n_classes, double *probsum_dev, int32_t *count_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_state_model_dev: null ctx");
+    SRX_ENTER(ctx, "srx_state_model_dev");
     SRX_REQUIRE(ctx, hmm && cls_dev && path_dev && status_dev && probsum_dev && count_dev && n_classes >= 1,
                 "srx_state_model_dev: bad argument");
     SRX_HIP(ctx, hipMemsetAsync(probsum_dev, 0, (size_t)n_classes * sizeof(double), ctx->stream));
@@ -206,7 +206,7 @@ extern "C" int srx_state_model_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const
 
 extern "C" int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev, const int32_t *status_dev,
                                      int64_t total_frames, int32_t *gid_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_em_gather_gid_dev: null ctx");
+    SRX_ENTER(ctx, "srx_em_gather_gid_dev");
     SRX_REQUIRE(ctx, hmm && path_dev && status_dev && gid_dev && total_frames >= 0, "srx_em_gather_gid_dev: bad argument");
     if (total_frames == 0 || hmm->n_utt == 0) return SRX_OK;
     {
@@ -229,7 +229,7 @@ int srx_em_accum_seg(srx_ctx *ctx, const float *feats, int ld, const int32_t *gi
 
 extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
                                 float *logp_dev, float *shift_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_em_shift_dev: null ctx");
+    SRX_ENTER(ctx, "srx_em_shift_dev");
     SRX_REQUIRE(ctx, A && feats_dev && gid_dev && logp_dev && shift_dev && T >= 0 && ld >= A->D, "srx_em_shift_dev: bad argument");
     {
         SrxProf prof_(ctx, "k_fill_f32");
@@ -303,14 +303,14 @@ static int launch_accum(srx_ctx *ctx, srx_model *A, srx_model *B, const float *f
 
 extern "C" int srx_em_pass1_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
                                 const float *logp_dev, const float *shift_dev, double *stats1_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_em_pass1_dev: null ctx");
+    SRX_ENTER(ctx, "srx_em_pass1_dev");
     SRX_REQUIRE(ctx, A && feats_dev && gid_dev && logp_dev && shift_dev && stats1_dev && T >= 0 && ld >= A->D,
                 "srx_em_pass1_dev: bad argument");
     return launch_accum<1>(ctx, A, nullptr, feats_dev, ld, gid_dev, T, logp_dev, shift_dev, stats1_dev);
 }
 
 extern "C" int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1_dev, const float *shift_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_em_means_dev: null ctx");
+    SRX_ENTER(ctx, "srx_em_means_dev");
     SRX_REQUIRE(ctx, B && stats1_dev && shift_dev, "srx_em_means_dev: null argument");
     const int64_t n = (int64_t)B->G * B->M * B->D;
     {
@@ -325,7 +325,7 @@ extern "C" int srx_em_means_dev(srx_ctx *ctx, srx_model *B, const double *stats1
 
 extern "C" int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const float *feats_dev, int ld, const int32_t *gid_dev,
                                 int64_t T, const float *logp_dev, const float *shift_dev, double *stats2_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_em_pass2_dev: null ctx");
+    SRX_ENTER(ctx, "srx_em_pass2_dev");
     SRX_REQUIRE(ctx, A && B && feats_dev && gid_dev && logp_dev && shift_dev && stats2_dev && T >= 0 && ld >= A->D,
                 "srx_em_pass2_dev: bad argument");
     SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_pass2_dev: model shape mismatch");
@@ -334,7 +334,7 @@ extern "C" int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const 
 
 extern "C" int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats1_dev, const double *stats2_dev,
                                  float blend_keep) {
-    SRX_REQUIRE(nullptr, ctx, "srx_em_finish_dev: null ctx");
+    SRX_ENTER(ctx, "srx_em_finish_dev");
     SRX_REQUIRE(ctx, A && B && stats1_dev && stats2_dev, "srx_em_finish_dev: null argument");
     SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_finish_dev: model shape mismatch");
     const int64_t n = (int64_t)B->G * B->M * B->D;

@@ -21,6 +21,7 @@
 // an SGPR.
 #include "srx_common.h"
 
+#include <mutex>
 #include <type_traits>
 
 // Emission prefetch depth in frames.  The frame loop is a dependent chain of about 0.06 us per step and an emission
@@ -52,8 +53,9 @@ static constexpr int BT_CH = 32;   // 16-frame back-pointer groups staged in LDS
 
 // One utterance with SPL states per lane.  The LDS arrays belong to the kernel (sized for the batch's widest utterance);
 // sl_alloc = 64 * that width is the row stride the back-pointer workspace was laid out with.
+// Returns true (no-beam bodies only) when the utterance has to be run again through the BEAM body: see `mx` below.
 template <int SPL, bool BEAM, int LAY, int PF>
-__device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
+__device__ __forceinline__ bool viterbi_utt(const int u, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                             const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
                                             const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
                                             const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
@@ -168,6 +170,16 @@ __device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restri
 #pragma unroll
     for (int q = 0; q < SPL; q++) bw[q] = 0;
     float cur_best = -1e10f;
+    // The reference applies `logp < current_best_logp - beam_width` even at its default width of 1e10
+    // (src/hmm.cpp:165): a source at -inf (zero-weight component, underflowed mixture) or more than 1e10 below the
+    // frame's best is skipped, and an utterance whose every candidate dies ends in NO PATH.  The no-beam bodies leave
+    // the test out and record the largest |delta| any state ever held instead: below 2.5e9 no two values of a frame
+    // are 1e10 apart (and none is below the -1e10 floor of current_best_logp), so the test could not have fired and
+    // the result is the reference's.  Otherwise the utterance is run again through the BEAM body with the width
+    // given, which carries the test and the "is the source in the map" flags exactly.
+    float mx[SPL], dprev[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; q++) mx[q] = dprev[q] = 0.0f;
 
     // Back-pointer words are indexed from the aligned start: frame t sits in word (t + a) >> 4 at bit pair (t + a) & 15.
     // Blocks start at multiples of PF from there and PF is a multiple of 16, so inside the unrolled block both the
@@ -244,6 +256,9 @@ __device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restri
                         dl[q] = t2 ? c2[q] : b1;
                         const uint32_t bp = t2 ? 2u : (t1 ? 1u : 0u);
                         bw[q] |= bp << (2 * (p & 15));
+                        // one v_max3 per two frames
+                        if (p & 1) mx[q] = fmaxf(fmaxf(mx[q], fabsf(dprev[q])), fabsf(dl[q]));
+                        else dprev[q] = dl[q];
                     }
                 } else {
                 if (BEAM) {
@@ -281,6 +296,8 @@ __device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restri
                     if (BEAM) {
                         act[q] = have;
                         nb = have ? fmaxf(nb, b2) : nb;
+                    } else {
+                        mx[q] = fmaxf(mx[q], fabsf(dl[q]));
                     }
                     bw[q] |= bp << (2 * (p & 15));
                 }
@@ -328,6 +345,12 @@ __device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restri
 #ifdef SRX_VIT_TIMING
     const long long tk2 = wall_clock64();
 #endif
+    if (!BEAM) {
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < SPL; q++) bad |= (lane * SPL + q < S) && !(mx[q] < 2.5e9f);   // also true for NaN
+        if (__any(bad)) return true;
+    }
     // ---- end condition: the path must end in the last state (src/hmm.cpp:210-215) ----
     const int last = S - 1;
     const int owner = last / SPL, oq = last % SPL;
@@ -348,7 +371,7 @@ __device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restri
     if (T < 1) reach = false;
     if (!reach) {
         if (lane == 0) status[u] = 1;
-        return;
+        return false;
     }
     if (lane == 0) {
         status[u] = 0;
@@ -432,6 +455,7 @@ __device__ __forceinline__ void viterbi_utt(const int u, const int64_t *__restri
         path[f0] = (int)(tk1 - tk0); path[f0 + 1] = (int)(tk2 - tk1); path[f0 + 2] = (int)(tk3 - tk2);
     }
 #endif
+    return false;
 }
 
 // One wavefront per utterance.  SPLMAX covers the batch's widest utterance; an utterance that fits fewer states per
@@ -450,15 +474,27 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     if (u >= n_utt) return;
     const int S = soff[u + 1] - soff[u];
     constexpr int PF1 = LAY == 1 ? SRX_VIT_PF_VEC : PF;   // the narrow bodies can afford the deep prefetch
+    // S beyond what the launch was sized for (hmm->max_states smaller than the batch's widest utterance) would overrun
+    // the LDS arrays: refuse that utterance instead
+    if (S > SLMAX || S < 1) {
+        if (threadIdx.x == 0) status[u] = 2;
+        return;
+    }
+    bool redo;
     if (SPLMAX >= 2 && S <= 64)
-        viterbi_utt<1, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status, dmin,
-                                       s_ntr, s_bp, SLMAX);
+        redo = viterbi_utt<1, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
+                                              dmin, s_ntr, s_bp, SLMAX);
     else if (SPLMAX >= 4 && S <= 128)
-        viterbi_utt<2, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status, dmin,
-                                       s_ntr, s_bp, SLMAX);
+        redo = viterbi_utt<2, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
+                                              dmin, s_ntr, s_bp, SLMAX);
     else
-        viterbi_utt<SPLMAX, BEAM, LAY, PF>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
+        redo = viterbi_utt<SPLMAX, BEAM, LAY, PF>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp,
+                                                  status, dmin, s_ntr, s_bp, SLMAX);
+    if (!BEAM && redo) {   // wave-uniform; rare (non-finite or absurdly large scores): the reference's pruning test decides
+        __syncthreads();
+        viterbi_utt<SPLMAX, true, LAY, PF>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, 1e10f, bpws, path, final_logp, status,
                                            dmin, s_ntr, s_bp, SLMAX);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -500,9 +536,15 @@ __global__ __launch_bounds__(256) void k_train_transitions(int n_utt, const int6
     }
 }
 
+static size_t viterbi_words(const srx_hmm_batch *hmm, int spl) {
+    return ((size_t)(hmm->total_frames >> 4) + (size_t)hmm->n_utt + 1) * 64 * spl;
+}
+
+// bpws == nullptr: back-pointer words from the context's grow-only workspace (may allocate); otherwise `bpws` holds
+// bpws_words words and nothing is allocated (no event pairs either: profiling brackets are skipped).
 static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t, int64_t stride_g,
-                          const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_viterbi_batch_dev: null ctx");
+                          const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev,
+                          uint32_t *bpws = nullptr, size_t bpws_words = 0) {
     SRX_REQUIRE(ctx, hmm && emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
     SRX_REQUIRE(ctx, hmm->frame_off_dev && hmm->state_off_dev && hmm->tied_dev && hmm->ntr_dev && hmm->trlogp_dev,
                 "srx_viterbi_batch_dev: null hmm field");
@@ -512,10 +554,17 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     const int64_t total_frames = hmm->total_frames;
     SRX_REQUIRE(ctx, total_frames >= 0, "srx_viterbi_batch_dev: negative total_frames");
     const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : 4);
-    const size_t words = ((size_t)(total_frames >> 4) + (size_t)hmm->n_utt + 1) * 64 * spl;
-    void *ws = nullptr;
-    int rc = srx_workspace(ctx, 1, words * sizeof(uint32_t), &ws);
-    if (rc != SRX_OK) return rc;
+    const size_t words = viterbi_words(hmm, spl);
+    void *ws = bpws;
+    if (bpws) {
+        SRX_REQUIRE(ctx, words <= bpws_words,
+                    "srx_viterbi_batch_noalloc_dev: %lld frames in %d utterances of up to %d states need %zu bytes of back-pointer words, "
+                    "the fixed scratch holds %zu (about %zu frames at this state width); use srx_viterbi_batch_dev",
+                    (long long)total_frames, hmm->n_utt, hmm->max_states, words * 4, bpws_words * 4, bpws_words / (64 * spl) * 16);
+    } else {
+        int rc = srx_workspace(ctx, 1, words * sizeof(uint32_t), &ws);
+        if (rc != SRX_OK) return rc;
+    }
     const bool beam = beam_width < 1e10f;
     dim3 grid(hmm->n_utt), block(64);
     const bool vec = !ebase_dev && stride_t == 1 && stride_g % 4 == 0 && stride_g >= total_frames &&
@@ -526,11 +575,16 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, LAYV, (LAYV == 1 ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF)>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
                        hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, ebase_dev, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
-    {
-        SrxProf prof_(ctx, "k_viterbi");
+    auto launch = [&]() {
         if (spl == 1) { if (beam) SRX_VIT(1, true); else SRX_VIT(1, false); }
         else if (spl == 2) { if (beam) SRX_VIT(2, true); else SRX_VIT(2, false); }
         else { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
+    };
+    if (bpws) {
+        launch();
+    } else {
+        SrxProf prof_(ctx, "k_viterbi");
+        launch();
     }
 #undef SRX_VIT
 #undef SRX_VIT2
@@ -540,20 +594,25 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
 
 extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
                                      int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
+    SRX_ENTER(ctx, "srx_viterbi_batch_dev");
     return viterbi_launch(ctx, hmm, emis_dev, stride_t, stride_g, nullptr, beam_width, path_dev, final_logp_dev, status_dev);
 }
 
+int srx_align_plan_n_utt(const srx_align_plan *plan);   // srx_gmm_f16_align.hip
+
 extern "C" int srx_viterbi_align_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const srx_align_plan *plan, const float *emis_dev,
                                      float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_viterbi_align_dev: null ctx");
-    SRX_REQUIRE(ctx, plan, "srx_viterbi_align_dev: null plan");
+    SRX_ENTER(ctx, "srx_viterbi_align_dev");
+    SRX_REQUIRE(ctx, plan && hmm, "srx_viterbi_align_dev: null plan or batch");
+    SRX_REQUIRE(ctx, srx_align_plan_n_utt(plan) == hmm->n_utt, "srx_viterbi_align_dev: plan is for %d utterances, batch has %d",
+                srx_align_plan_n_utt(plan), hmm->n_utt);
     return viterbi_launch(ctx, hmm, emis_dev, 1, 0, srx_align_plan_emission_offsets_dev(plan), beam_width, path_dev, final_logp_dev,
                           status_dev);
 }
 
 extern "C" int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,
                                          const int32_t *status_dev) {
-    SRX_REQUIRE(nullptr, ctx, "srx_train_transitions_dev: null ctx");
+    SRX_ENTER(ctx, "srx_train_transitions_dev");
     SRX_REQUIRE(ctx, hmm && path_dev && status_dev, "srx_train_transitions_dev: null argument");
     SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 256, "srx_train_transitions_dev: max_states outside 1..256");
     if (hmm->n_utt == 0) return SRX_OK;

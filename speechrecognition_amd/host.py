@@ -329,6 +329,17 @@ class HmmBatch:
     def train_transition_probabilities(self, path_d, status_d):
         check(self.ctx.lib.srx_train_transitions_dev(self.ctx.h, C.byref(self.c), path_d.ptr, status_d.ptr), self.ctx.h)
 
+    def state_model(self, cls, path_d, status_d, n_classes):
+        """state_model::augment over every frame of every final path (src/hmm.cpp:46-51, 350-356): cls[n_states] = tied
+        class of each state (-1: skip) -> (probsum f64 [C], count i32 [C])."""
+        ctx = self.ctx
+        cls_d = ctx.array(np.ascontiguousarray(cls, np.int32))
+        ps, cnt = ctx.empty((n_classes,), np.float64), ctx.empty((n_classes,), np.int32)
+        check(ctx.lib.srx_state_model_dev(ctx.h, C.byref(self.c), cls_d.ptr, path_d.ptr, status_d.ptr, n_classes, ps.ptr, cnt.ptr),
+              ctx.h)
+        ctx.sync()
+        return ps.get(), cnt.get()
+
     # ---- alignment-mode scoring: each utterance against its own states, compact emissions ----
     def align_plan(self):
         """Layout of the compact emission buffer (utterance u: frame-major block [T_u][S_u] at emis_off[u])."""

@@ -222,3 +222,101 @@ def test_config4_training_iteration_10k_utterances(ctx, oracle):
     np.testing.assert_allclose(gw[pick], rw[pick], rtol=3e-7)
     A.close()
     B.close()
+
+
+def test_config5_training_iteration_100k_utterances_compact_emissions(ctx, oracle):
+    """BASELINE config 5 on the path it really uses: 100,000 utterances (~5e7 frames, 7.8 GB of features) through
+    alignment-mode scoring (k_gmm_f16_align, 8 GB of compact emissions), the compact-layout Viterbi, transition
+    re-estimation and the sort-by-state segmented statistics (parallel.TrainingShard(emissions="compact"), the object
+    bench.py's training leg and the multi-GPU path run).  Same checks as config 4: path topology on every
+    utterance, gid == tied id of the aligned state on every frame, weights of visited states sum to 1, and the
+    oracle's statistics (long double) on the frames of 6 sampled states at rtol 1e-9; plus the oracle's Viterbi
+    (bit-exact score and path) on sampled utterances from the compact emission blocks the kernel wrote."""
+    torch = _torch()
+    from speechrecognition_amd import parallel
+    n = 100_000
+    ntrs, trs, tieds, fo = _alignment_corpus(n, 8)
+    T = int(fo[-1])
+    assert 4.8e7 < T < 5.2e7
+    mean, var, w = synth.random_model(G, M, D, 777)
+    dev = torch.device("cuda", ctx.device)
+    # frames drawn around the states of a plausible (uniform) alignment, generated on the device
+    S = np.array([len(t) for t in tieds], np.int64)
+    soff = np.concatenate([[0], np.cumsum(S)])
+    tied_flat = np.concatenate(tieds)
+    Tlen = np.diff(fo)
+    utt_of = np.repeat(np.arange(n, dtype=np.int64), Tlen)
+    lt = np.arange(T, dtype=np.int64) - fo[utt_of]
+    g_true = tied_flat[soff[utt_of] + np.minimum(lt * S[utt_of] // Tlen[utt_of], S[utt_of] - 1)]
+    del lt
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(9)
+    g_t = torch.as_tensor(g_true, device=dev, dtype=torch.int64)
+    c_t = torch.randint(0, M, (T,), device=dev, generator=gen)
+    mean_t = torch.as_tensor(mean, device=dev, dtype=torch.float32)
+    sd_t = torch.as_tensor(np.sqrt(var), device=dev, dtype=torch.float32)
+    feats_t = torch.empty((T, D), dtype=torch.float32, device=dev)
+    step = 1 << 22
+    for a in range(0, T, step):
+        b = min(T, a + step)
+        row = g_t[a:b] * M + c_t[a:b]
+        feats_t[a:b] = mean_t.view(G * M, D)[row] + torch.randn((b - a, D), device=dev, generator=gen) * sd_t.view(G * M, D)[row]
+    del g_t, c_t, g_true
+    torch.cuda.synchronize()
+    feats_d = host.DevArray.wrap(ctx, feats_t.data_ptr(), (T, D), np.float32, feats_t)
+    A = host.AcousticModel(ctx, G, M, D)
+    B = host.AcousticModel(ctx, G, M, D)
+    A.set(mean, var, w)
+    B.copy_from(A)
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, mix_mode=SRX_MIX_LOGSUMEXP, score_path=SRX_SCORE_MFMA_F16X3,
+                                   emissions="compact")
+    assert hb.emis_count * 4 > 7e9          # the 8 GB compact buffer
+    shard.iteration(A, A, B, 0.2)
+    ctx.sync()
+    path, status, gid = shard.path.get(), shard.status.get(), shard.gid.get()
+    _check_paths(path, status, fo, ntrs)
+    assert np.array_equal(gid, tied_flat[path + soff[utt_of]])
+    rng = np.random.default_rng(10)
+    # Viterbi against the oracle on the very emissions the scoring kernel wrote (compact blocks [T_u][S_u])
+    final = shard.final.get()
+    emis_t = torch.empty(0)
+    for u in rng.choice(n, 12, replace=False):
+        a, b = int(hb.emis_off[u]), int(hb.emis_off[u + 1])
+        blk = np.empty(b - a, np.float32)
+        from speechrecognition_amd._capi import check
+        check(ctx.lib.srx_memcpy_d2h(ctx.h, blk.ctypes.data, shard.emis.ptr.value + 4 * a, 4 * (b - a)), ctx.h)
+        e = blk.reshape(int(Tlen[u]), int(S[u]))
+        r = oracle.viterbi(e, np.arange(S[u], dtype=np.int32), ntrs[u], trs[u], 1e10, 0)
+        assert r["status"] == 0 and final[u].tobytes() == r["final"].tobytes()
+        assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"])
+        # and the emissions themselves against the oracle's long-double scores on a few frames
+        fr = rng.choice(int(Tlen[u]), 3, replace=False)
+        f39 = np.zeros((3, 39), np.float32)
+        f39[:, :D] = feats_t[torch.as_tensor(fo[u] + fr, device=dev)].cpu().numpy()
+        ref = oracle.gmm_score(f39, mean, var, oracle.set_wt(w), D, SRX_MIX_LOGSUMEXP)[:, tieds[u]]
+        assert (np.abs(e[fr] - ref) <= 1e-4 * np.maximum(np.abs(ref), 1.0)).all()
+    # statistics
+    s1 = shard.stats1.get().reshape(G, M, 1 + D)
+    count = np.bincount(gid, minlength=G)
+    gm, gv, gw = B.get()
+    seen = count > 0
+    assert seen.all() and (s1[:, :, 0] > 0).all()
+    np.testing.assert_allclose(gw.sum(axis=1), 1.0, rtol=2e-6)
+    assert (gv > 0).all() and np.isfinite(gm).all()
+    pick = rng.choice(G, 6, replace=False)
+    sel = np.flatnonzero(np.isin(gid, pick))
+    f39 = np.zeros((len(sel), 39), np.float32)
+    f39[:, :D] = feats_t[torch.as_tensor(sel, device=dev)].cpu().numpy()
+    rm, rv, rw, _, _ = oracle.em_statistics(f39, gid[sel], D, mean, var, w, 0.2)
+    np.testing.assert_allclose(gm[pick], rm[pick].astype(np.float64), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gv[pick], rv[pick].astype(np.float64), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gw[pick], rw[pick], rtol=3e-7)
+    # the transitions of sampled utterances follow the oracle's re-estimation of their paths
+    got_tr = hb.trlogp()
+    for u in rng.choice(n, 20, replace=False):
+        want = oracle.train_transitions(path[fo[u]:fo[u + 1]], ntrs[u], trs[u])
+        np.testing.assert_allclose(got_tr[soff[u]:soff[u + 1]], want, rtol=3e-6, atol=1e-7)
+    hb.close()
+    A.close()
+    B.close()

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from speechrecognition_amd import SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP, host, synth
+from speechrecognition_amd._capi import SRX_SCORE_EXACT
 from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3 as F16
 
 pytestmark = pytest.mark.gpu
@@ -116,13 +117,21 @@ def test_outlier_and_nan_frames_are_reevaluated_exactly(ctx, oracle):
     for mode in (SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP):
         ref = oracle.gmm_score(feats, mean, var, lw, D, mode)
         got = model.score(feats, mode, F16)
-        fin = np.isfinite(ref)
-        assert np.array_equal(np.isnan(got), np.isnan(ref)) or mode == SRX_MIX_LOGSUMEXP
-        assert _close(got[fin], ref[fin]).all(), (mode, np.abs(got[fin] - ref[fin]).max())
-        assert np.isnan(got[499]).all() or mode == SRX_MIX_LOGSUMEXP
-        # component-0 scores of the outlier rows are finite and huge: they must match, not saturate
-        if mode == SRX_MIX_COMPONENT0:
-            assert np.isfinite(ref[7]).all() and np.abs(ref[7]).min() > 1e6
+        exact = model.score(feats, mode, SRX_SCORE_EXACT)
+        if mode == SRX_MIX_LOGSUMEXP:
+            # The reference's (commented-out) form log(sum exp(g_m)) underflows to -inf on the outlier rows; one -inf frame
+            # removes its utterance through the pruning test of src/hmm.cpp:165.  The library takes the sum relative to the
+            # largest component there (a stated divergence; parity unpinned: dead code in the reference):
+            # expected values from the oracle's per-component log-densities combined in numpy with a shift.
+            assert np.isneginf(ref[7]).all() and np.isneginf(ref[300]).all()
+            ref[[7, 300]] = oracle.gmm_score_shifted(feats[[7, 300]], mean, var, lw, D)
+        assert np.isfinite(ref[[7, 300]]).all() and np.abs(ref[7]).min() > 1e6
+        for g_ in (got, exact):
+            assert np.array_equal(np.isnan(g_), np.isnan(ref)), mode
+            assert np.isnan(g_[499]).all()
+            fin = ~np.isnan(ref)
+            assert np.isfinite(g_[fin]).all(), mode
+            assert _close(g_[fin], ref[fin]).all(), (mode, np.abs(g_[fin] - ref[fin]).max())
     model.close()
 
 

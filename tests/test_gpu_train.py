@@ -68,3 +68,53 @@ def test_gather_gid_skips_no_path(ctx):
     st = s.get()
     assert st[0] == 1 and st[1] == 0
     assert (gid[:2] == -1).all() and set(gid[2:]) <= {7, 8, 9}
+
+
+def test_state_model_augment_against_oracle(ctx, oracle):
+    """a24: state_model::augment over every frame of every final path (src/hmm.cpp:46-51, 350-356) and
+    state_model::operator() (:39-44).  The reference keeps f32 running sums in path order, the kernel f64 atomics:
+    counts are exact; sums agree with the oracle's f32 running sums at rtol 2e-5 (f32 accumulation error of <= 1e4
+    terms) and with an f64 sum of the same f32 terms at 1e-6 (device expf vs libm expf, <= 1 ulp per term).
+    The last state of a training HMM has one transition: get_adv_prob() reads tr[1] out of bounds there in the
+    reference (UB); those frames carry class -1 and are skipped on both sides."""
+    rng = np.random.default_rng(71)
+    G, C_ = 40, 23
+    ntrs, trs, tieds, Ts, clss = [], [], [], [], []
+    for u in range(30):
+        ph = synth.phone_string(rng, 5)
+        ntr, tr, _ = host.build_training_hmm(ph)
+        ntrs.append(ntr); trs.append(tr)
+        tieds.append(rng.integers(0, G, len(ph)).astype(np.int32))
+        Ts.append(int(rng.integers(4 if u == 0 else 120, 5 if u == 0 else 400)))     # utterance 0: too short -> NO PATH
+        c = rng.integers(0, C_ - 1, len(ph)).astype(np.int32)     # class C_-1 is never seen -> operator() gives 0.5
+        c[-1] = -1
+        clss.append(c)
+    fo = np.zeros(len(Ts) + 1, np.int64)
+    fo[1:] = np.cumsum(Ts)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 15).astype(np.float32)
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    path_d, final_d, status_d = hb.viterbi(ctx.array(emis), G)
+    for _ in range(2):
+        hb.train_transition_probabilities(path_d, status_d)
+    ctx.sync()
+    path, status, tr = path_d.get(), status_d.get(), hb.trlogp()
+    assert status[0] == 1 and (status[1:] == 0).all()
+    ps, cnt = hb.state_model(np.concatenate(clss), path_d, status_d, C_)
+    # the same frames, in path order, for the oracle
+    cls_t, adv_t = [], []
+    for u in range(1, len(Ts)):
+        st = path[fo[u]:fo[u + 1]]
+        c = clss[u][st]
+        a = np.exp(tr[hb.state_off[u] + st, 1].astype(np.float32)).astype(np.float32)
+        keep = c >= 0
+        cls_t.append(c[keep]); adv_t.append(a[keep])
+    cls_t, adv_t = np.concatenate(cls_t), np.concatenate(adv_t)
+    rps, rcnt = oracle.state_model(cls_t, adv_t, C_)
+    assert np.array_equal(cnt, rcnt) and cnt[C_ - 1] == 0 and cnt.sum() == len(cls_t)
+    np.testing.assert_allclose(ps, rps.astype(np.float64), rtol=2e-5)
+    np.testing.assert_allclose(ps, np.bincount(cls_t, adv_t.astype(np.float64), C_), rtol=1e-6)
+    # state_model::operator(): pooled mean, 0.5 where nothing was seen
+    pooled = np.where(cnt > 0, ps / np.maximum(cnt, 1), 0.5)
+    ref = np.where(rcnt > 0, rps / np.maximum(rcnt, 1).astype(np.float32), np.float32(0.5))
+    np.testing.assert_allclose(pooled, ref, rtol=2e-5)
+    assert pooled[C_ - 1] == 0.5

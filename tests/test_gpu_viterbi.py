@@ -145,3 +145,33 @@ def test_train_transition_probabilities(ctx, oracle):
         for u in range(len(ntrs)):
             trs[u] = oracle.train_transitions(path[fo[u]:fo[u + 1]], ntrs[u], trs[u])
             np.testing.assert_allclose(got[so[u]:so[u + 1]], trs[u], rtol=3e-6, atol=1e-7)
+
+
+def test_viterbi_nonfinite_and_huge_emissions_follow_the_reference_pruning_test(ctx, oracle):
+    """The reference keeps `logp < current_best_logp - beam_width` at its default width of 1e10 (src/hmm.cpp:165):
+    a source at -inf (zero-weight component) or 1e10 below the frame's best is skipped, and a frame whose emissions
+    are all -inf leaves `next` empty -> NO PATH (status 1), not a path of garbage back-pointers.  Every layout."""
+    rng = np.random.default_rng(61)
+    G = 30
+    _, ntrs, trs, tieds, fo = _make_batch(rng, 10, G, 60, 200, words=4)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 20).astype(np.float32)
+    ninf = np.float32(-np.inf)
+    # utt 0: one frame with every emission -inf -> NO PATH
+    emis[fo[0] + 17, :] = ninf
+    # utt 1: one state's column -inf for a stretch (the path has to route around / through it)
+    emis[fo[1] + 5:fo[1] + 12, tieds[1][2]] = ninf
+    # utt 2: the first frame all -inf -> NO PATH
+    emis[fo[2], :] = ninf
+    # utt 3: the last frame all -inf
+    emis[fo[4] - 1, :] = ninf
+    # utt 4: finite but absurd magnitudes: a frame 3e10 below everything (pruned at 1e10 in the reference) ...
+    emis[fo[4] + 9, :] = np.float32(-3e10)
+    # utt 5: ... and a single state 3e10 below the others for some frames
+    emis[fo[5] + 20:fo[5] + 26, tieds[5][1]] = np.float32(-3e10)
+    # utt 6: -inf everywhere except one frame
+    emis[fo[6] + 1:fo[7], :] = ninf
+    _, _, _, _, status = _check(ctx, oracle, ntrs, trs, tieds, fo, emis)
+    assert status[0] == 1 and status[2] == 1 and status[7] == 0 and status[8] == 0 and status[9] == 0
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major=True)
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major="aligned")
+    _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam=50.0)
