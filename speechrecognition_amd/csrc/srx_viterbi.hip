@@ -21,7 +21,6 @@
 // an SGPR.
 #include "srx_common.h"
 
-#include <mutex>
 #include <type_traits>
 
 // Emission prefetch depth in frames.  The frame loop is a dependent chain of about 0.06 us per step and an emission
@@ -540,11 +539,8 @@ static size_t viterbi_words(const srx_hmm_batch *hmm, int spl) {
     return ((size_t)(hmm->total_frames >> 4) + (size_t)hmm->n_utt + 1) * 64 * spl;
 }
 
-// bpws == nullptr: back-pointer words from the context's grow-only workspace (may allocate); otherwise `bpws` holds
-// bpws_words words and nothing is allocated (no event pairs either: profiling brackets are skipped).
 static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t, int64_t stride_g,
-                          const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev,
-                          uint32_t *bpws = nullptr, size_t bpws_words = 0) {
+                          const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
     SRX_REQUIRE(ctx, hmm && emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
     SRX_REQUIRE(ctx, hmm->frame_off_dev && hmm->state_off_dev && hmm->tied_dev && hmm->ntr_dev && hmm->trlogp_dev,
                 "srx_viterbi_batch_dev: null hmm field");
@@ -555,16 +551,9 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     SRX_REQUIRE(ctx, total_frames >= 0, "srx_viterbi_batch_dev: negative total_frames");
     const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : 4);
     const size_t words = viterbi_words(hmm, spl);
-    void *ws = bpws;
-    if (bpws) {
-        SRX_REQUIRE(ctx, words <= bpws_words,
-                    "srx_viterbi_batch_noalloc_dev: %lld frames in %d utterances of up to %d states need %zu bytes of back-pointer words, "
-                    "the fixed scratch holds %zu (about %zu frames at this state width); use srx_viterbi_batch_dev",
-                    (long long)total_frames, hmm->n_utt, hmm->max_states, words * 4, bpws_words * 4, bpws_words / (64 * spl) * 16);
-    } else {
-        int rc = srx_workspace(ctx, 1, words * sizeof(uint32_t), &ws);
-        if (rc != SRX_OK) return rc;
-    }
+    void *ws = nullptr;
+    int rc = srx_workspace(ctx, 1, words * sizeof(uint32_t), &ws);
+    if (rc != SRX_OK) return rc;
     const bool beam = beam_width < 1e10f;
     dim3 grid(hmm->n_utt), block(64);
     const bool vec = !ebase_dev && stride_t == 1 && stride_g % 4 == 0 && stride_g >= total_frames &&
@@ -580,9 +569,7 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
         else if (spl == 2) { if (beam) SRX_VIT(2, true); else SRX_VIT(2, false); }
         else { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
     };
-    if (bpws) {
-        launch();
-    } else {
+    {
         SrxProf prof_(ctx, "k_viterbi");
         launch();
     }
