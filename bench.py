@@ -114,6 +114,144 @@ def cpu_baseline(x, soff, ntrs, trs, tieds, model, budget_s=20.0):
     }
 
 
+def alignment_corpus(n_utt, seed):
+    """BASELINE configs 3/4: T ~ U{200..800} frames, 4-12 words x 2-6 phones with SIL between, tied ids
+    uniform in [0, G).  Deterministic in (n_utt, seed): every rank generates the same descriptors and keeps its shard."""
+    from speechrecognition_amd import synth
+    rng = np.random.default_rng(seed)
+    phones, tieds, Ts = [], [], np.empty(n_utt, np.int64)
+    for u in range(n_utt):
+        ph = synth.phone_string(rng, int(rng.integers(4, 13)))
+        phones.append(ph)
+        tieds.append(rng.integers(0, G, len(ph)).astype(np.int32))
+        Ts[u] = int(rng.integers(200, 801))
+    return phones, tieds, Ts
+
+
+def build_shard(ctx, torch, host, parallel, phones, tieds, Ts, rank, world, seed):
+    """This rank's share of the corpus (greedy balance of frames x states), resident on its GPU: HMM batch + features
+    ~ N(0, 1.3^2) generated on the device (config 3's features)."""
+    costs = Ts * np.array([len(p) for p in phones], np.int64)
+    mine = parallel.shard_utterances(costs, world)[rank]
+    hm = [host.build_training_hmm(phones[u]) for u in mine]
+    fo = np.zeros(len(mine) + 1, np.int64)
+    fo[1:] = np.cumsum(Ts[mine])
+    hb = host.HmmBatch(ctx, fo, [h[0] for h in hm], [h[1] for h in hm], [tieds[u] for u in mine])
+    T = int(fo[-1])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed + rank)
+    feats_t = torch.randn((max(T, 1), D), device="cuda", generator=gen) * 1.3
+    feats_d = host.DevArray.wrap(ctx, feats_t.data_ptr(), (max(T, 1), D), np.float32, feats_t)
+    flop = 2.0 * (2 * D + 1) * M * float(sum(len(phones[u]) * Ts[u] for u in mine))
+    return hb, feats_d, T, flop
+
+
+def reduce_max_sum(torch, dist, backend, vals_max, vals_sum):
+    tm = torch.tensor(vals_max, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    ts = torch.tensor(vals_sum, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    return tm.tolist(), ts.tolist()
+
+
+def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
+    """BASELINE config 5: one embedded-training iteration (hmm::train, src/hmm.cpp:254-347) over n_total utterances
+    split across the ranks (STRONG scaling: the corpus is fixed, each rank holds 1/world of it): alignment-mode scoring,
+    Viterbi, transition re-estimation, statistics, the three all-reduces (RCCL under nccl), blend.  Timed with a barrier
+    and a device synchronisation on both sides; the slowest rank counts."""
+    from speechrecognition_amd import SRX_MIX_LOGSUMEXP, host, parallel, synth
+    from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3
+    phones, tieds, Ts = alignment_corpus(n_total, 4)
+    hb, feats_d, T, flop = build_shard(ctx, torch, host, parallel, phones, tieds, Ts, rank, world, 1000)
+    O, A, B = (host.AcousticModel(ctx, G, M, D) for _ in range(3))
+    O.set(*synth.random_model(G, M, D, 777))
+    A.copy_from(O)
+    B.copy_from(O)
+    ex = parallel.Exchange()
+    shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, ex, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3, emissions="compact")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warm):
+        shard.iteration(O, A, B, 0.2)
+        A, B = B, A
+    barrier()
+    shard.time_collectives = True
+    ex.bytes_reduced = 0
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        shard.iteration(O, A, B, 0.2)        # Viterbi under the utterances' own model object (SURVEY.md fact 12)
+        A, B = B, A
+    barrier()
+    dt = time.perf_counter() - t0
+    coll = {k: float(np.mean(v)) for k, v in shard.collective_ms().items()}
+    kern = {}
+    for k in ("k_gmm_f16_align", "k_viterbi", "k_train_transitions", "k_gather_gid", "em_sort", "em_radix_sort", "k_em_logp_seg",
+              "k_em_accum_seg1", "k_em_accum_seg2", "k_em_seg_reduce", "k_em_means", "k_em_finish"):
+        ms, n = ctx.profile_query(k)
+        if n:
+            kern[k] = ms / iters
+    ctx.profile_enable(False)
+    assert (shard.status.get()[:hb.n_utt] == 0).all(), "alignment failed for some utterance"
+    (dt_max,), (frames_all, flop_all) = reduce_max_sum(torch, dist, backend, [dt], [float(T), flop])
+    ms_it = dt_max / iters * 1e3
+    out = {"workload": f"configs[4]: one embedded-training iteration over {n_total} utterances split across {world} GPU(s) "
+                       "(alignment-mode scoring + Viterbi + transitions + statistics + 3 all-reduces + blend)",
+           "scaling": "strong", "utterances_total": n_total, "frames_total": frames_all, "iterations_timed": iters,
+           "ms_per_iteration": ms_it, "frames_per_s": frames_all / (ms_it * 1e-3),
+           "rank0_kernels_ms_per_iteration": kern, "rank0_collectives_ms": coll,
+           "collective_bytes_per_iteration": {"max_shift_f32": G * M * 4, "sum_stats1_f64": G * M * (1 + D) * 8,
+                                              "sum_stats2_f64": G * M * D * 8},
+           "bytes_reduced_per_iteration_counted": ex.bytes_reduced / max(iters, 1),
+           "align_scoring_algorithmic_TFLOPs_rank0": (flop / (kern["k_gmm_f16_align"] * 1e-3) / 1e12) if kern.get("k_gmm_f16_align") else None}
+    hb.close()
+    for m_ in (O, A, B):
+        m_.close()
+    return out
+
+
+def alignment_leg(ctx, torch, dist, backend, rank, world, n_total, reps):
+    """BASELINE config 3/4: forced alignment of n_total utterances split across the ranks (strong scaling): alignment-mode
+    scoring + Viterbi, no collective (utterances are independent)."""
+    from speechrecognition_amd import SRX_MIX_LOGSUMEXP, host, parallel, synth
+    from speechrecognition_amd._capi import SRX_SCORE_MFMA_F16X3
+    phones, tieds, Ts = alignment_corpus(n_total, 6)
+    hb, feats_d, T, _ = build_shard(ctx, torch, host, parallel, phones, tieds, Ts, rank, world, 2000)
+    model = host.AcousticModel(ctx, G, M, D)
+    model.set(*synth.random_model(G, M, D, 777))
+    hb.align_plan()
+    emis = ctx.empty((max(hb.emis_count, 1),), np.float32)
+    path_d, final_d, status_d = ctx.zeros((max(T, 1),), np.int32), ctx.zeros((hb.n_utt,), np.float32), ctx.zeros((hb.n_utt,), np.int32)
+
+    def once():
+        hb.score_align(model, feats_d, D, emis, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3)
+        hb.viterbi_align(emis, 1e10, path_d, final_d, status_d)
+
+    once()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert (status_d.get() == 0).all()
+    (dt_max,), (frames_all,) = reduce_max_sum(torch, dist, backend, [dt], [float(T)])
+    hb.close()
+    model.close()
+    return {"workload": f"configs[3]: forced alignment of {n_total} utterances split across {world} GPU(s)", "scaling": "strong",
+            "utterances_total": n_total, "frames_total": frames_all, "ms_per_pass": dt_max / reps * 1e3,
+            "frames_per_s": frames_all * reps / dt_max}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +260,9 @@ def main():
     ap.add_argument("--utts", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--frame-major", action="store_true", help="emission matrix as [T][G] instead of [G][T]")
+    ap.add_argument("--train-utts", type=int, default=100000, help="config-5 training leg: utterances in the whole corpus (0: skip)")
+    ap.add_argument("--train-iters", type=int, default=5)
+    ap.add_argument("--align-utts", type=int, default=10000, help="config-3/4 alignment leg: utterances in the whole corpus (0: skip)")
     ap.add_argument("--score-path", choices=["f16x3", "f32"], default="f16x3",
                     help="GMM scoring kernel: split-f16 MFMA (default) or f32-input MFMA")
     args = ap.parse_args()
@@ -234,6 +375,25 @@ def main():
     else:
         dt_max, frames_all = dt, float(T)
 
+    # ---- the like-for-like precision figure: the f32-input matrix-core kernel on the same batch (not in the headline) ----
+    extra = {}
+    if args.score_path == "f16x3":
+        ctx.profile_enable(True)
+        for _ in range(3):
+            model.score_dev(feats_d, 3 * NCEPS, T, emis_d, ST_T, ST_G, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA)
+        ms32, n32 = ctx.profile_query("k_gmm_mfma")
+        ctx.profile_enable(False)
+        tf32 = 2.0 * (2 * D + 1) * G * M * T / (ms32 / n32 * 1e-3) / 1e12
+        extra["gmm_f32_path"] = {"kernel": "k_gmm_mfma<16,4>", "ms_per_launch": ms32 / n32, "achieved_TFLOPs": tf32,
+                                 "peak_TFLOPs": PEAK_F32_MFMA_TFLOPS, "frac": tf32 / PEAK_F32_MFMA_TFLOPS,
+                                 "note": "same contraction with f32 inputs (exact f32 products); --score-path f32 makes it the headline path"}
+    # ---- free the headline buffers, then the strong-scaling legs over BASELINE configs 3-5 ----
+    del emis_d, x_d, ceps_d
+    if args.align_utts > 0:
+        extra["align_config4"] = alignment_leg(ctx, torch, dist, backend, rank, world, args.align_utts, 5)
+    if args.train_utts > 0:
+        extra["train_config5"] = training_leg(ctx, torch, dist, backend, rank, world, args.train_utts, args.train_iters, 2)
+
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
         flop_per_frame = 2.0 * (2 * D + 1) * G * M          # GMM scoring, all states
@@ -260,11 +420,12 @@ def main():
             # against the f32-input MFMA peak (the only other way to hold the 1e-4 bar) see "vs_f32_mfma_peak".
             "roofline": {"bound": "mfma", "achieved": gmm_tflops, "peak": gmm_peak, "unit": "TFLOP/s",
                          "frac": gmm_tflops / gmm_peak, "traffic": pmc_traffic(gmm_kernel, T),
+                         "traffic_source": "committed PMC pass (profiles/pmc_traffic.json: separate rocprofv3 --pmc runs of this workload), not measured in this run",
                          "kernel": "k_gmm_f16<16,5>" if f16 else "k_gmm_mfma<16,4>", "flop_per_frame": flop_per_frame,
                          "ms_per_launch": kernel_ms[gmm_kernel], "executed_over_algorithmic_flops": 3 if f16 else 1,
                          "mfma_executed_frac_of_peak": (3 if f16 else 1) * gmm_tflops / gmm_peak,
                          "vs_f32_mfma_peak": gmm_tflops / PEAK_F32_MFMA_TFLOPS},
-            "stages_ms": stage_ms, "kernels_ms": kernel_ms,
+            "stages_ms": stage_ms, "kernels_ms": kernel_ms, "extra": extra,
             "stage_rooflines": {
                 "mfcc_hbm": {"kernel": mfcc_kernel, "achieved_GBs": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9,
                              "peak_GBs": PEAK_HBM_GBS, "frac": mfcc_bytes / (mfcc_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

@@ -44,6 +44,10 @@ int srx_ctx_create(int device, void *stream, srx_ctx **out);
 void srx_ctx_destroy(srx_ctx *ctx);
 const char *srx_last_error(const srx_ctx *ctx); /* ctx may be NULL: last creation error */
 int srx_sync(srx_ctx *ctx);
+/* The hipStream_t the context launches on (the one given to srx_ctx_create, or its own).  No counterpart in the reference
+ * (which has no streams): lets a caller order its own work -- copies, RCCL collectives, torch ops -- against libsrx's
+ * kernels on the device instead of calling srx_sync. */
+void *srx_ctx_stream(const srx_ctx *ctx);
 const char *srx_version(void);
 
 /* Per-kernel timing with HIP events on the context's stream.  No counterpart in the reference (which has

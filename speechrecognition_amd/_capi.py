@@ -49,6 +49,7 @@ SIGNATURES = {
     "srx_ctx_destroy": (None, [vp]),
     "srx_last_error": (C.c_char_p, [vp]),
     "srx_sync": (C.c_int, [vp]),
+    "srx_ctx_stream": (vp, [vp]),
     "srx_version": (C.c_char_p, []),
     "srx_profile_enable": (C.c_int, [vp, C.c_int]),
     "srx_profile_query": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -93,6 +93,8 @@ int srx_workspace(srx_ctx *ctx, int slot, size_t bytes, void **out) {
 
 extern "C" const char *srx_last_error(const srx_ctx *ctx) { return ctx ? ctx->err : g_srx_create_err; }
 
+extern "C" void *srx_ctx_stream(const srx_ctx *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
 extern "C" int srx_sync(srx_ctx *ctx) {
     SRX_ENTER(ctx, "srx_sync");
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));

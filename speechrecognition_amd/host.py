@@ -39,6 +39,10 @@ class Context:
     def sync(self):
         check(self.lib.srx_sync(self.h), self.h)
 
+    def stream_handle(self):
+        """The hipStream_t this context launches on, as an integer (for torch.cuda.ExternalStream)."""
+        return int(self.lib.srx_ctx_stream(self.h) or 0)
+
     def profile_enable(self, on=True):
         """Start (and clear) / stop per-kernel event timing on this context's stream."""
         check(self.lib.srx_profile_enable(self.h, int(on)), self.h)

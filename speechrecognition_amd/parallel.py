@@ -84,20 +84,45 @@ class TrainingShard:
         self.t_shift = torch.empty(G * M, dtype=torch.float32, device=dev)
         self.t_stats1 = torch.empty(G * M * (1 + D), dtype=torch.float64, device=dev)
         self.t_stats2 = torch.empty(G * M * D, dtype=torch.float64, device=dev)
+        # the context's stream as a torch stream: collectives are enqueued relative to it (see _collective)
+        self.tstream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+        self.time_collectives = False
+        self.collective_events = []
         self.shift = host.DevArray.wrap(ctx, self.t_shift.data_ptr(), (G * M,), np.float32, self.t_shift)
         self.stats1 = host.DevArray.wrap(ctx, self.t_stats1.data_ptr(), (G * M * (1 + D),), np.float64, self.t_stats1)
         self.stats2 = host.DevArray.wrap(ctx, self.t_stats2.data_ptr(), (G * M * D,), np.float64, self.t_stats2)
 
-    def _collective(self, fn, t):
-        """libsrx launches on the context's stream, torch.distributed orders the collective after torch's
-        current stream: bracket the exchange with host-side waits on both (three per iteration; the
-        reduced buffers are <= 10 MB, SURVEY.md 8e, so the exchange itself is short)."""
+    def _collective(self, fn, t, name):
+        """libsrx launches on the context's stream; torch.distributed orders a collective after torch's CURRENT stream and
+        makes that stream wait for it.  The exchange therefore runs with the context's stream as torch's current stream
+        (an ExternalStream over the same handle): producer kernel -> all-reduce -> consumer kernel are ordered on the
+        device, with no host-side wait (round 1 bracketed every collective with two stream synchronisations).  With
+        `time_collectives` an event pair on that stream brackets each exchange."""
         if not self.ex.active:
             return
+        if not t.is_cuda:
+            self.ctx.sync()          # host tensors (CPU rehearsal): the producer kernel has to be done
+            fn(t)
+            return
+        torch = self.torch
+        with torch.cuda.stream(self.tstream):
+            if self.time_collectives:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(self.tstream)
+                fn(t)
+                b.record(self.tstream)
+                self.collective_events.append((name, a, b))
+            else:
+                fn(t)
+
+    def collective_ms(self):
+        """Synchronises and returns {name: [ms, ...]} of the timed exchanges since the last call."""
         self.ctx.sync()
-        fn(t)
-        if t.is_cuda:
-            self.torch.cuda.current_stream(t.device).synchronize()
+        out = {}
+        for name, a, b in self.collective_events:
+            out.setdefault(name, []).append(a.elapsed_time(b))
+        self.collective_events = []
+        return out
 
     def iteration(self, vit_model, A, B, keep=0.2):
         """align under `vit_model`, re-estimate transitions, rebuild B from statistics under A (all ranks end
@@ -115,12 +140,12 @@ class TrainingShard:
             hb.train_transition_probabilities(self.path, self.status)
             check(lib.srx_em_gather_gid_dev(ctx.h, hb.c_ref(), self.path.ptr, self.status.ptr, T, self.gid.ptr), ctx.h)
         check(lib.srx_em_shift_dev(ctx.h, A.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr, self.shift.ptr), ctx.h)
-        self._collective(self.ex.allreduce_max, self.t_shift)
+        self._collective(self.ex.allreduce_max, self.t_shift, "max_shift_f32")
         check(lib.srx_em_pass1_dev(ctx.h, A.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr, self.shift.ptr,
                                    self.stats1.ptr), ctx.h)
-        self._collective(self.ex.allreduce_sum, self.t_stats1)
+        self._collective(self.ex.allreduce_sum, self.t_stats1, "sum_stats1_f64")
         check(lib.srx_em_means_dev(ctx.h, B.h, self.stats1.ptr, self.shift.ptr), ctx.h)
         check(lib.srx_em_pass2_dev(ctx.h, A.h, B.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr,
                                    self.shift.ptr, self.stats2.ptr), ctx.h)
-        self._collective(self.ex.allreduce_sum, self.t_stats2)
+        self._collective(self.ex.allreduce_sum, self.t_stats2, "sum_stats2_f64")
         check(lib.srx_em_finish_dev(ctx.h, A.h, B.h, self.stats1.ptr, self.stats2.ptr, keep), ctx.h)
