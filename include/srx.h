@@ -152,6 +152,13 @@ int srx_features_batch(srx_ctx *ctx, int WL, int n_ceps, const float *ceps, cons
 int srx_corpus_mean_var_dev(srx_ctx *ctx, const float *feats_dev, int ld, int64_t total_frames, int D,
                             double *sum_dev /*[2*D] scratch+result: sums then sum of squares*/);
 
+/* One half of mean(ut) / variance(ut, mu) for a shard of the corpus: mu_dev == NULL -> out_dev[d] = sum_t x[t][d]
+ * (src/utterance.cpp:36-41); otherwise out_dev[d] = sum_t (x[t][d] - mu[d])^2 with the f32 difference and square of
+ * src/utterance.cpp:55-58.  The sums of all shards are added (srx_allreduce_sum_f64_dev) before the division by the
+ * global frame count. */
+int srx_corpus_sums_dev(srx_ctx *ctx, const float *feats_dev, int ld, int64_t total_frames, int D, const float *mu_dev,
+                        double *out_dev /*[D]*/);
+
 /* ---------------------------------------------------------------- acoustic model ---- */
 typedef struct srx_model srx_model;
 
@@ -279,6 +286,35 @@ int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const float *feat
                      double *stats2_dev);
 int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats1_dev, const double *stats2_dev,
                       float blend_keep);
+
+/* ---------------------------------------------------------------- multi-GPU exchange --- */
+/* One process per GPU, utterances sharded across the ranks; MFCC, scoring and alignment need no communication.  What
+ * the ranks exchange are the sums that the reference's sequential loops over all utterances build:
+ *   per EM iteration  MAX of shift[G*M] f32 (after srx_em_shift_dev), SUM of stats1[G*M*(1+D)] f64 (after
+ *                     srx_em_pass1_dev; src/hmm.cpp:275-287, 298-316), SUM of stats2[G*M*D] f64 (after srx_em_pass2_dev;
+ *                     src/hmm.cpp:319-338) -- every rank then rebuilds the identical model;
+ *   once at the end   SUM of the state-model tables of srx_state_model_dev (src/hmm.cpp:350-356);
+ *   before training   SUM of the corpus sums of srx_corpus_sums_dev (mean / variance, src/utterance.cpp:32-65).
+ * All-reduces are in place on device buffers, asynchronous on the context's stream (ordered with the kernels around
+ * them), RCCL over xGMI.  world == 1 makes every call a no-op, so a single-GPU run takes the same path.
+ *
+ * srx_comm_unique_id: rank 0 obtains SRX_COMM_ID_BYTES opaque bytes (ncclGetUniqueId) and hands them to the other
+ * ranks out of band (file, environment, the launcher's store); srx_comm_create joins (collective over the ranks; one
+ * GPU per rank).  srx_comm_create_host is a REHEARSAL transport for ranks that share one GPU, which RCCL refuses:
+ * buffers cross a POSIX shared-memory segment `shm_name` ("/name") and are summed on the host in rank order.  It exists
+ * so that multi-rank control flow can be tested on a one-GPU box; it is not a data path. */
+typedef struct srx_comm srx_comm;
+enum { SRX_COMM_ID_BYTES = 128 };
+int srx_comm_unique_id(void *id_out);
+int srx_comm_create(srx_ctx *ctx, int rank, int world, const void *id, srx_comm **out);
+int srx_comm_create_host(srx_ctx *ctx, int rank, int world, const char *shm_name, srx_comm **out);
+void srx_comm_destroy(srx_comm *comm);
+int srx_comm_rank(const srx_comm *comm);
+int srx_comm_world(const srx_comm *comm);
+int64_t srx_comm_bytes_reduced(const srx_comm *comm); /* payload bytes handed to all-reduces so far */
+int srx_allreduce_max_f32_dev(srx_comm *comm, float *buf_dev, int64_t n);
+int srx_allreduce_sum_f64_dev(srx_comm *comm, double *buf_dev, int64_t n);
+int srx_allreduce_sum_i32_dev(srx_comm *comm, int32_t *buf_dev, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ SIGNATURES = {
     "srx_features_batch_dev": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, i64, vp]),
     "srx_features_batch": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "srx_corpus_mean_var_dev": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, vp]),
+    "srx_corpus_sums_dev": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, vp, vp]),
     "srx_model_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "srx_model_destroy": (None, [vp]),
     "srx_model_set": (C.c_int, [vp, vp, vp, vp]),
@@ -99,6 +100,16 @@ SIGNATURES = {
     "srx_em_means_dev": (C.c_int, [vp, vp, vp, vp]),
     "srx_em_pass2_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp, vp]),
     "srx_em_finish_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_float]),
+    "srx_comm_unique_id": (C.c_int, [vp]),
+    "srx_comm_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "srx_comm_create_host": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
+    "srx_comm_destroy": (None, [vp]),
+    "srx_comm_rank": (C.c_int, [vp]),
+    "srx_comm_world": (C.c_int, [vp]),
+    "srx_comm_bytes_reduced": (i64, [vp]),
+    "srx_allreduce_max_f32_dev": (C.c_int, [vp, vp, i64]),
+    "srx_allreduce_sum_f64_dev": (C.c_int, [vp, vp, i64]),
+    "srx_allreduce_sum_i32_dev": (C.c_int, [vp, vp, i64]),
 }
 
 _lib = None

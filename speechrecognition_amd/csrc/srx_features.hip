@@ -145,11 +145,12 @@ extern "C" int srx_features_batch(srx_ctx *ctx, int WL, int n_ceps, const float 
 // f = f32(x - mu), f*f in f32 as the reference, accumulated in f64 (the reference keeps f32 running
 // sums; f64 here is the more accurate of the two -- documented divergence).
 __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ feats, int ld, int64_t T, int D,
-                                                const double *__restrict__ mu_sum, double *__restrict__ out, int pass) {
+                                                const double *__restrict__ mu_sum, double *__restrict__ out, int pass,
+                                                const float *__restrict__ mu_given) {
     const int d = blockIdx.y;
     double acc = 0.0;
     float mu = 0.0f;
-    if (pass == 1) mu = (float)mu_sum[d] / (float)(int)T;
+    if (pass == 1) mu = mu_given ? mu_given[d] : (float)mu_sum[d] / (float)(int)T;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
         float v = feats[t * ld + d];
         if (pass == 1) {
@@ -174,12 +175,28 @@ extern "C" int srx_corpus_mean_var_dev(srx_ctx *ctx, const float *feats_dev, int
     int nb = (int)(ceil_div64(total_frames, 256) < 1024 ? ceil_div64(total_frames, 256) : 1024);
     {
         SrxProf prof_(ctx, "k_colsum");
-        hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev, 0);
+        hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev, 0, nullptr);
     }
     SRX_LAUNCH_CHECK(ctx);
     {
         SrxProf prof_(ctx, "k_colsum");
-        hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev + D, 1);
+        hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, sum_dev, sum_dev + D, 1, nullptr);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+extern "C" int srx_corpus_sums_dev(srx_ctx *ctx, const float *feats_dev, int ld, int64_t total_frames, int D, const float *mu_dev,
+                                   double *out_dev) {
+    SRX_ENTER(ctx, "srx_corpus_sums_dev");
+    SRX_REQUIRE(ctx, out_dev && D >= 1 && ld >= D && total_frames >= 0 && (feats_dev || total_frames == 0), "srx_corpus_sums_dev: bad argument");
+    SRX_HIP(ctx, hipMemsetAsync(out_dev, 0, D * sizeof(double), ctx->stream));
+    if (total_frames == 0) return SRX_OK;   // an empty shard contributes zeros
+    int nb = (int)(ceil_div64(total_frames, 256) < 1024 ? ceil_div64(total_frames, 256) : 1024);
+    {
+        SrxProf prof_(ctx, "k_colsum");
+        hipLaunchKernelGGL(k_colsum, dim3(nb, D), dim3(256), 0, ctx->stream, feats_dev, ld, total_frames, D, (const double *)nullptr, out_dev,
+                           mu_dev ? 1 : 0, mu_dev);
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;

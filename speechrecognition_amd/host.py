@@ -411,3 +411,40 @@ def gather_gid(ctx, hmm, path_d, status_d):
     gid = ctx.empty((max(hmm.total_frames, 1),), np.int32)
     check(ctx.lib.srx_em_gather_gid_dev(ctx.h, C.byref(hmm.c), path_d.ptr, status_d.ptr, hmm.total_frames, gid.ptr), ctx.h)
     return gid
+
+
+# ----------------------------------------------------------------------------- multi-GPU exchange
+class Comm:
+    """srx_comm: the all-reduces of sufficient statistics behind the C ABI (RCCL; world 1 = no-ops)."""
+
+    def __init__(self, ctx, rank=0, world=1, uid=None, shm_name=None):
+        self.ctx = ctx
+        h = C.c_void_p()
+        if shm_name is not None:
+            check(ctx.lib.srx_comm_create_host(ctx.h, rank, world, shm_name.encode(), C.byref(h)), ctx.h)
+        else:
+            check(ctx.lib.srx_comm_create(ctx.h, rank, world, uid, C.byref(h)), ctx.h)
+        self.h = h
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(_capi.load().srx_comm_unique_id(buf))
+        return buf
+
+    def allreduce_max_f32(self, a):
+        check(self.ctx.lib.srx_allreduce_max_f32_dev(self.h, a.ptr, int(np.prod(a.shape))), self.ctx.h)
+
+    def allreduce_sum_f64(self, a):
+        check(self.ctx.lib.srx_allreduce_sum_f64_dev(self.h, a.ptr, int(np.prod(a.shape))), self.ctx.h)
+
+    def allreduce_sum_i32(self, a):
+        check(self.ctx.lib.srx_allreduce_sum_i32_dev(self.h, a.ptr, int(np.prod(a.shape))), self.ctx.h)
+
+    def bytes_reduced(self):
+        return int(self.ctx.lib.srx_comm_bytes_reduced(self.h))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.srx_comm_destroy(self.h)
+            self.h = None

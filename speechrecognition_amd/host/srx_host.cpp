@@ -3,6 +3,7 @@
 // libsrx.so.  No arithmetic of the hot path is performed here; file I/O, containers and bookkeeping only.
 #include "srx_host.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +11,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <time.h>
 
 using std::string;
 using std::vector;
@@ -18,6 +20,8 @@ using std::vector;
 namespace {
 
 srx_ctx *g_ctx = nullptr;
+srx_comm *g_comm = nullptr;
+int g_rank = 0, g_world = 1;
 bool g_verbose = false;
 
 void check(int rc) {
@@ -91,7 +95,9 @@ int g_score_path = env_choice("SRX_SCORE_PATH", "f16x3", env_choice("SRX_SCORE_P
 namespace srx {
 srx_ctx *context() {
     if (!g_ctx) {
+        // one process per GPU: SRX_DEVICE, else the launcher's LOCAL_RANK, else device 0
         const char *d = std::getenv("SRX_DEVICE");
+        if (!d) d = std::getenv("LOCAL_RANK");
         int rc = srx_ctx_create(d ? std::atoi(d) : 0, nullptr, &g_ctx);
         if (rc != SRX_OK) {
             const char *m = srx_last_error(nullptr);
@@ -100,6 +106,83 @@ srx_ctx *context() {
     }
     return g_ctx;
 }
+// The communicator every exchange of this layer goes through.  World 1 (no launcher) is a communicator whose
+// collectives are no-ops, so the single-GPU run takes the same path.
+srx_comm *communicator() {
+    if (!g_comm) {
+        int rc = srx_comm_create(context(), 0, 1, nullptr, &g_comm);
+        if (rc != SRX_OK) throw srx_error(rc, srx_last_error(g_ctx));
+    }
+    return g_comm;
+}
+int rank() { return g_rank; }
+int world() { return g_world; }
+
+// Joins the ranks of one launch (RANK / WORLD_SIZE in the environment, as torchrun, mpirun wrappers and SLURM scripts set
+// them).  The 128-byte id of rank 0 travels through the file SRX_COMM_FILE (any path all ranks can read: rank 0 writes
+// <file>.tmp and renames it, the others wait for it).  SRX_COMM_SHM=/name selects the host rehearsal transport instead
+// (ranks sharing one GPU, see include/srx.h).
+void init_distributed() {
+    const char *r = std::getenv("RANK"), *w = std::getenv("WORLD_SIZE");
+    if (!r || !w || std::atoi(w) <= 1 || g_comm) return;
+    g_rank = std::atoi(r);
+    g_world = std::atoi(w);
+    srx_ctx *ctx = context();
+    int rc;
+    if (const char *shm = std::getenv("SRX_COMM_SHM")) {
+        rc = srx_comm_create_host(ctx, g_rank, g_world, shm, &g_comm);
+    } else {
+        const char *file = std::getenv("SRX_COMM_FILE");
+        if (!file) throw srx_error(SRX_ERR_INVALID, "WORLD_SIZE > 1 needs SRX_COMM_FILE (where rank 0 publishes the RCCL id) or SRX_COMM_SHM");
+        unsigned char id[SRX_COMM_ID_BYTES];
+        if (g_rank == 0) {
+            rc = srx_comm_unique_id(id);
+            if (rc != SRX_OK) throw srx_error(rc, srx_last_error(nullptr));
+            string tmp = string(file) + ".tmp";
+            FILE *f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) throw srx_error(SRX_ERR_IO, "cannot write " + tmp);
+            std::fclose(f);
+            if (std::rename(tmp.c_str(), file) != 0) throw srx_error(SRX_ERR_IO, string("cannot publish ") + file);
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 6000 && !got; tries++) {   // up to 60 s
+                FILE *f = std::fopen(file, "rb");
+                if (f) {
+                    got = std::fread(id, 1, sizeof id, f) == sizeof id;
+                    std::fclose(f);
+                }
+                if (!got) {
+                    struct timespec ts = {0, 10 * 1000 * 1000};
+                    nanosleep(&ts, nullptr);
+                }
+            }
+            if (!got) throw srx_error(SRX_ERR_IO, string("rank 0 never published ") + file);
+        }
+        rc = srx_comm_create(ctx, g_rank, g_world, id, &g_comm);
+    }
+    if (rc != SRX_OK) throw srx_error(rc, srx_last_error(ctx));
+}
+
+// Greedy longest-processing-time partition of the utterances over the ranks (cost = frames x states): sorted by cost
+// descending (stable), each to the currently lightest rank; ascending indices within a rank.  Deterministic: every rank
+// computes the same partition.  (speechrecognition_amd/parallel.py::shard_utterances is the same rule.)
+vector<int> shard_utterances(const vector<double> &costs, int world_, int rank_) {
+    vector<int> order(costs.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return costs[a] > costs[b]; });
+    vector<double> load((size_t)world_, 0.0);
+    vector<int> mine;
+    for (int u : order) {
+        int best = 0;
+        for (int k = 1; k < world_; k++)
+            if (load[k] < load[best]) best = k;
+        load[best] += costs[u];
+        if (best == rank_) mine.push_back(u);
+    }
+    std::sort(mine.begin(), mine.end());
+    return mine;
+}
+
 void set_verbose(bool on) { g_verbose = on; }
 // A generator of this layer's own: libc's rand() is shared with whatever else the process loads, and draws made
 // on the device runtime's threads made random initialisation differ from run to run.
@@ -756,6 +839,9 @@ struct DeviceBatch {
         }
     }
     void upload() {
+        if (foff.empty()) foff.push_back(0);   // an empty shard: zero utterances, every array still allocated
+        if (soff.empty()) soff.push_back(0);
+        if (tied.empty()) { d_tied.alloc(1); d_ntr.alloc(1); d_tr.alloc(3); }
         d_foff.upload(foff);
         d_soff.upload(soff);
         d_tied.upload(tied);
@@ -840,8 +926,9 @@ void hmm::train(vector<utterance> &ut) { train(ut, EM_ITERS); }
 
 void hmm::train(vector<utterance> &ut, int iterations) {
     if (!temp_acm) throw srx_error(SRX_ERR_INVALID, "hmm::train: this hmm was not constructed as a trainer");
-    if (ut.empty()) return;
     srx_ctx *ctx = srx::context();
+    srx_comm *comm = srx::communicator();
+    if (ut.empty() && srx_comm_world(comm) == 1) return;   // (a rank with an empty shard still takes part in the exchanges)
     // ---- corpus -> device, once ----
     vector<float> x;
     DeviceBatch b;
@@ -855,10 +942,11 @@ void hmm::train(vector<utterance> &ut, int iterations) {
     const int64_t T = b.c.total_frames;
     const int ld = 3 * NPARAMS;
     Dev<float> d_x;
-    d_x.upload(x);
+    if (x.empty()) d_x.alloc(ld);
+    else d_x.upload(x);
     // every utterance HMM keeps the acoustic_model it was built with (src/utterance.cpp:20) while this object
     // swaps acm / temp_acm each iteration (src/hmm.cpp:344-346): Viterbi runs under the utterances' model
-    acoustic_model *vit_model = ut[0].hmm->acm;
+    acoustic_model *vit_model = ut.empty() ? acm : ut[0].hmm->acm;
     const int G = vit_model->num_states(), M = acm->num_mix();
     // Emissions: the split-f16 and exact score paths look up only each utterance's own states, as hmm::viterbi does
     // (src/hmm.cpp:166), into compact per-utterance blocks; the f32 matrix-core path fills the dense [G][T] matrix.
@@ -876,7 +964,9 @@ void hmm::train(vector<utterance> &ut, int iterations) {
     for (int it = 1; it <= iterations; it++) {
         if (srx::verbose()) std::cout << "----------------------Iteration " << it << "-------------------------" << std::endl;
         // Viterbi paths for each utterance (src/hmm.cpp:257-267), emissions state-major [G][T]
-        if (compact) {
+        if (T == 0) {
+            // an empty shard: nothing to align, the statistics below contribute zeros to the exchanges
+        } else if (compact) {
             check(srx_gmm_score_align_dev(ctx, vit_model->device(), g_mix_mode, g_score_path, d_x.p, ld, &b.c, plan.p, d_e.p));
             check(srx_viterbi_align_dev(ctx, &b.c, plan.p, d_e.p, 1e10f, d_path.p, d_final.p, d_status.p));
         } else {
@@ -897,14 +987,20 @@ void hmm::train(vector<utterance> &ut, int iterations) {
             }
         }
         // transition probabilities of the utterance HMMs (src/hmm.cpp:269-271)
-        check(srx_train_transitions_dev(ctx, &b.c, d_path.p, d_status.p));
+        if (T > 0) check(srx_train_transitions_dev(ctx, &b.c, d_path.p, d_status.p));
         // mixture parameters (src/hmm.cpp:272-341): statistics under acm, rebuilt into temp_acm
-        check(srx_em_gather_gid_dev(ctx, &b.c, d_path.p, d_status.p, T, d_gid.p));
+        if (T > 0) check(srx_em_gather_gid_dev(ctx, &b.c, d_path.p, d_status.p, T, d_gid.p));
         srx_model *A = acm->device(), *B = temp_acm->device();
+        // `ut` is this rank's shard of the corpus: the sums of the reference's three sequential loops over ALL utterances
+        // (src/hmm.cpp:275, 298, 319) are completed across the ranks at the three points below (world 1: no-ops); every
+        // rank then rebuilds the identical temp_acm
         check(srx_em_shift_dev(ctx, A, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p));
+        check(srx_allreduce_max_f32_dev(comm, d_shift.p, (int64_t)G * M));
         check(srx_em_pass1_dev(ctx, A, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p, d_s1.p));
+        check(srx_allreduce_sum_f64_dev(comm, d_s1.p, (int64_t)G * M * (1 + FV_LEN)));
         check(srx_em_means_dev(ctx, B, d_s1.p, d_shift.p));
         check(srx_em_pass2_dev(ctx, A, B, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p, d_s2.p));
+        check(srx_allreduce_sum_f64_dev(comm, d_s2.p, (int64_t)G * M * FV_LEN));
         check(srx_em_finish_dev(ctx, A, B, d_s1.p, d_s2.p, GMM_BLEND_FAC));
         // swap references (src/hmm.cpp:344-346)
         acoustic_model *t = acm;
@@ -917,30 +1013,31 @@ void hmm::train(vector<utterance> &ut, int iterations) {
     temp_acm->download();
     // lexicon-HMM parameters from the final paths (src/hmm.cpp:350-357)
     if (sm && sm->ties) {
-        std::map<phone::context, int> cls_of;
-        vector<phone::context> cls_ctx;
+        // classes are numbered by the tied context itself, (prev * 40 + curr) * 40 + next, so that every rank sums into
+        // the same table and the tables add up across ranks
+        const int C = phone::NUM_PH * phone::NUM_PH * phone::NUM_PH;
         vector<int32_t> cls;
         for (hmm *h : hs)
             for (hmm_state &st : h->states) {
                 phone::context c = (*sm->ties)(st.ctx);
-                auto f = cls_of.find(c);
-                if (f == cls_of.end()) {
-                    f = cls_of.insert(std::make_pair(c, (int)cls_ctx.size())).first;
-                    cls_ctx.push_back(c);
-                }
-                cls.push_back(st.tr.size() >= 2 ? f->second : -1);  // get_adv_prob reads tr[1]
+                const int id = ((int)c.prev * phone::NUM_PH + (int)c.curr) * phone::NUM_PH + (int)c.next;
+                cls.push_back(st.tr.size() >= 2 ? id : -1);  // get_adv_prob reads tr[1]: absent on a last state (UB in the reference)
             }
-        const int C = (int)cls_ctx.size();
         Dev<int32_t> d_cls, d_cnt((size_t)C);
         Dev<double> d_sum((size_t)C);
-        d_cls.upload(cls);
+        if (cls.empty()) d_cls.alloc(1);
+        else d_cls.upload(cls);
         check(srx_state_model_dev(ctx, &b.c, d_cls.p, d_path.p, d_status.p, C, d_sum.p, d_cnt.p));
+        check(srx_allreduce_sum_f64_dev(comm, d_sum.p, C));
+        check(srx_allreduce_sum_i32_dev(comm, d_cnt.p, C));
         vector<double> sum = d_sum.get();
         vector<int32_t> cnt = d_cnt.get();
         for (int c = 0; c < C; c++)
             if (cnt[c] > 0) {
-                sm->probsums[cls_ctx[c]] += (float)sum[c];
-                sm->counts[cls_ctx[c]] += cnt[c];
+                phone::context k((phone::phone)(c / (phone::NUM_PH * phone::NUM_PH)), (phone::phone)(c / phone::NUM_PH % phone::NUM_PH),
+                                 (phone::phone)(c % phone::NUM_PH));
+                sm->probsums[k] += (float)sum[c];
+                sm->counts[k] += cnt[c];
             }
     }
     update_states();
@@ -968,35 +1065,42 @@ utterance::utterance(const string &t, const vector<phone::phone> &pron, const ve
     : text(t), pronunciation(pron), hmm(new class hmm(pron, &acm)), features(fv) {}
 
 namespace {
-void corpus_sums(vector<utterance> &ut, vector<double> &sums, int64_t &T) {
+// sum over this rank's frames, completed across the ranks: out[0..FV_LEN) the column sums (mu == nullptr) or the sums of
+// squared f32 differences to mu; returns the global frame count
+int64_t corpus_sums(vector<utterance> &ut, const float *mu, vector<double> &sums) {
     vector<float> x;
     for (utterance &u : ut) pack_features(u.features, x);
-    T = (int64_t)(x.size() / (3 * NPARAMS));
-    sums.assign(2 * FV_LEN, 0.0);
-    if (T == 0) return;
-    Dev<float> d_x;
-    d_x.upload(x);
-    Dev<double> d_s(2 * FV_LEN);
-    check(srx_corpus_mean_var_dev(srx::context(), d_x.p, 3 * NPARAMS, T, FV_LEN, d_s.p));
-    check(srx_sync(srx::context()));
-    d_s.download(sums.data(), sums.size());
+    const int64_t T = (int64_t)(x.size() / (3 * NPARAMS));
+    srx_ctx *ctx = srx::context();
+    Dev<float> d_x, d_mu(FV_LEN);
+    if (x.empty()) d_x.alloc(3 * NPARAMS);
+    else d_x.upload(x);
+    if (mu) d_mu.upload(mu, FV_LEN);
+    Dev<double> d_s(FV_LEN + 1);
+    check(srx_corpus_sums_dev(ctx, d_x.p, 3 * NPARAMS, T, FV_LEN, mu ? d_mu.p : nullptr, d_s.p));
+    const double t_local = (double)T;
+    check(srx_memcpy_h2d(ctx, d_s.p + FV_LEN, &t_local, sizeof(double)));
+    check(srx_allreduce_sum_f64_dev(srx::communicator(), d_s.p, FV_LEN + 1));
+    check(srx_sync(ctx));
+    sums = d_s.get();
+    return (int64_t)sums[FV_LEN];
 }
 }  // namespace
 
+// mean(ut) / variance(ut, mu), src/utterance.cpp:32-65, over the utterances of ALL ranks (each rank passes its shard).
 featurevec mean(vector<utterance> &ut) {
     vector<double> s;
-    int64_t T;
-    corpus_sums(ut, s, T);
+    const int64_t T = corpus_sums(ut, nullptr, s);
     featurevec mu;
     for (int j = 0; j < FV_LEN; j++) mu[j] = (float)s[j] / (float)(int)T;
     return mu;
 }
-featurevec variance(vector<utterance> &ut, featurevec &) {
-    // the device routine recomputes the mean itself (same value as mean(ut))
+featurevec variance(vector<utterance> &ut, featurevec &mu) {
     vector<double> s;
-    int64_t T;
-    corpus_sums(ut, s, T);
+    float m[FV_LEN];
+    for (int j = 0; j < FV_LEN; j++) m[j] = mu[j];
+    const int64_t T = corpus_sums(ut, m, s);
     featurevec var;
-    for (int j = 0; j < FV_LEN; j++) var[j] = (float)(s[FV_LEN + j] / (double)T);
+    for (int j = 0; j < FV_LEN; j++) var[j] = (float)(s[j] / (double)T);
     return var;
 }

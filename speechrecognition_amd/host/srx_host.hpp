@@ -64,6 +64,13 @@ public:
 
 namespace srx {
 srx_ctx *context();            // the process-wide context (device SRX_DEVICE or 0), created on first use
+// Multi-GPU (no counterpart in the reference, which is one process): one process per GPU, each holding a shard of the
+// utterances; hmm::train, mean and variance complete their sums over all ranks through this communicator.
+void init_distributed();       // joins the launch described by RANK / WORLD_SIZE / LOCAL_RANK (+ SRX_COMM_FILE); no-op without
+srx_comm *communicator();      // world-1 communicator (collectives are no-ops) unless init_distributed joined a launch
+int rank();
+int world();
+std::vector<int> shard_utterances(const std::vector<double> &costs, int world, int rank);   // this rank's utterance indices
 void set_verbose(bool on);     // the reference prints constantly (e.g. src/mfcc.cpp:279, src/hmm.cpp:217); default off
 bool verbose();
 void seed_random(unsigned seed);   // generator behind gaussian::initialize (the reference draws from ofRandom there)

@@ -5,6 +5,8 @@
 //   srx --mode mfcc  --voxforge DIR/ [--list _list]  [--window 320 --shift 160] [--batch 256] [--verbose]
 //   srx --mode train --voxforge DIR/ [--list _train] [--iters 80] [--mix 1] [--seed 1] [--out model.txt]
 //   srx --mode align --voxforge DIR/ [--list _train] [--model model.txt] [--out paths.txt]
+//   RANK=r WORLD_SIZE=n LOCAL_RANK=g SRX_COMM_FILE=/shared/path srx --mode train ...    one process per GPU: every rank
+//        loads its share of the utterances, statistics are all-reduced with RCCL, rank 0 writes --out
 //   srx --mode pronounce --lexicon cmu.txt [--prefixes prefixes.txt --suffixes suffixes.txt]   (text lines on stdin)
 //
 // train/align take the same --lexicon/--prefixes/--suffixes: with a lexicon the transcripts are read from
@@ -19,6 +21,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <algorithm>
 #include <sstream>
 
 #include "srx_host.hpp"
@@ -88,21 +91,60 @@ static int run_mfcc(const string &dir, const string &list, unsigned wl, unsigned
     return 0;
 }
 
+// One utterance per PROMPTS / PHONES line (src/main.cpp:41-50).  Under a multi-rank launch every rank walks the same
+// lists, prices each line (frames from the 4-byte header of its .mfc file x states of its pronunciation), takes its
+// share by srx::shard_utterances and loads only that.
 static void load_corpus(const string &dir, const string &list, acoustic_model &acm, vector<utterance> &ut, pronouncer *pron) {
     vector<string> folders = readlines(dir + list);
+    vector<string> lines;
     for (size_t i = 0; i < folders.size(); i++) {
         if (folders[i].empty()) continue;
         ifstream prompts((dir + folders[i] + (pron ? "etc/PROMPTS" : "etc/PHONES")).c_str());
-        while (prompts.good() && prompts.peek() != EOF) {
+        string line;
+        while (getline(prompts, line))
+            if (line.find_first_not_of(" \t\r") != string::npos) lines.push_back(line);
+    }
+    vector<char> mine(lines.size(), 1);
+    if (srx::world() > 1) {
+        vector<double> costs(lines.size(), 0.0);
+        for (size_t k = 0; k < lines.size(); k++) {
+            istringstream in(lines[k]);
+            string mfc, text;
+            in >> mfc;
+            getline(in, text);
+            double states = 1, frames = 0;
             try {
-                ut.push_back(pron ? utterance(prompts, dir, acm, *pron) : utterance(prompts, dir, acm));
-            } catch (int ex) {
-                cout << "Caught exception " << ex << endl;  // src/main.cpp:44-48
+                if (pron) states = (double)pron->pronounce(text).size();
+                else {
+                    istringstream ss(text);
+                    string tok;
+                    states = 0;
+                    while (ss >> tok) states++;
+                }
+            } catch (int) {
+                states = 0;   // unpronounceable: the constructor below throws for it on its owner, as in the reference
             }
-            prompts >> ws;
+            if (FILE *f = fopen((dir + mfc).c_str(), "rb")) {
+                int32_t n = 0;
+                if (fread(&n, sizeof n, 1, f) == 1 && n > 0) frames = n;
+                fclose(f);
+            }
+            costs[k] = frames * states;
+        }
+        fill(mine.begin(), mine.end(), 0);
+        for (int k : srx::shard_utterances(costs, srx::world(), srx::rank())) mine[(size_t)k] = 1;
+    }
+    for (size_t k = 0; k < lines.size(); k++) {
+        if (!mine[k]) continue;
+        istringstream in(lines[k]);
+        try {
+            ut.push_back(pron ? utterance(in, dir, acm, *pron) : utterance(in, dir, acm));
+        } catch (int ex) {
+            cout << "Caught exception " << ex << endl;  // src/main.cpp:44-48
         }
     }
-    cout << "Got " << ut.size() << " utterances" << endl;
+    if (srx::world() > 1) cout << "rank " << srx::rank() << " of " << srx::world() << ": ";
+    cout << "Got " << ut.size() << " utterances" << (srx::world() > 1 ? " of " + to_string(lines.size()) : string()) << endl;
 }
 
 static void dump_model(acoustic_model &acm, const string &fname) {
@@ -183,13 +225,14 @@ int main(int argc, char **argv) {
             return run_mfcc(dir, arg(argc, argv, "--list", "_list"), (unsigned)atoi(arg(argc, argv, "--window", "320").c_str()),
                             (unsigned)atoi(arg(argc, argv, "--shift", "160").c_str()), atoi(arg(argc, argv, "--batch", "256").c_str()));
         if (mode == "train" || mode == "align") {
+            srx::init_distributed();   // RANK / WORLD_SIZE / LOCAL_RANK of a launcher; a plain run is world 1
             srx::seed_random((unsigned)atoi(arg(argc, argv, "--seed", "1").c_str()));
             phone::ties acm_ties(phone::ties::NULL_CONTEXT);   // src/main.cpp:34-36
             phone::ties hmm_ties(phone::ties::PHONE_CLASSES);
             acoustic_model acm(acm_ties, atoi(arg(argc, argv, "--mix", "1").c_str()));
             vector<utterance> ut;
             load_corpus(dir, arg(argc, argv, "--list", "_train"), acm, ut, pron);
-            if (ut.empty()) return 1;
+            if (ut.empty() && srx::world() == 1) return 1;
             const string model_in = arg(argc, argv, "--model", "");
             if (!model_in.empty()) {
                 if (!load_model(acm, model_in)) {
@@ -205,7 +248,7 @@ int main(int argc, char **argv) {
                 hmm h(&acm, new state_model(&hmm_ties));    // src/main.cpp:58 (trainer object; no lexicon topology)
                 h.train(ut, atoi(arg(argc, argv, "--iters", "80").c_str()));
                 const string out = arg(argc, argv, "--out", "");
-                if (!out.empty()) dump_model(*h.acm, out);
+                if (!out.empty() && (srx::rank() == 0 || flag(argc, argv, "--dump-every-rank"))) dump_model(*h.acm, out);   // every rank holds the same model
                 cout << "trained " << h.acm->num_states() << " tied states on " << ut.size() << " utterances" << endl;
             } else {
                 const string out = arg(argc, argv, "--out", "");

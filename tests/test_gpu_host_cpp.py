@@ -221,6 +221,52 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
     # mean/variance initialisation path (src/main.cpp:52-54; random jitter, so only that it runs and writes a model)
     _run([SRX, "--mode", "train", "--voxforge", root, "--iters", "1", "--out", root + "rand.txt"], env)
     assert open(root + "rand.txt").readline().split() == ["srx-model", "40", "1", "13"]
+
+    # ---- the same runs as a TWO-RANK launch of the C++ driver: each rank loads its share of the utterances, hmm::train /
+    # mean / variance complete their sums through the communicator of the C ABI (srx_comm_*).  Both ranks sit on this
+    # box's one GPU, which RCCL refuses, so the exchange goes through the host rehearsal transport (SRX_COMM_SHM); the
+    # RCCL calls themselves are exercised by test_comm_rccl_single_rank below and by the driver's multi-GPU bench.
+    def nums(fn, tag):
+        return np.array([[float(v) for v in ln.split()[1:]] for ln in open(fn).read().split("\n") if ln.startswith(tag)])
+
+    def launch2(args, outs):
+        shm = "/srx_t_%d_%d" % (os.getpid(), rng.integers(1 << 30))
+        ps = []
+        for r in range(2):
+            e2 = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", SRX_COMM_SHM=shm, **env)
+            ps.append(subprocess.Popen([SRX] + args + ["--out", outs[r], "--dump-every-rank"], env=e2, stdout=subprocess.PIPE,
+                                       stderr=subprocess.STDOUT, text=True))
+        texts = []
+        for p_ in ps:
+            try:
+                o, _ = p_.communicate(timeout=110)
+            except subprocess.TimeoutExpired:
+                for q in ps:
+                    q.kill()
+                raise
+            texts.append(o)
+        for r, p_ in enumerate(ps):
+            assert p_.returncode == 0, (r, texts[r][-2000:])
+        return texts
+
+    outs = [root + "trained_r0.txt", root + "trained_r1.txt"]
+    texts = launch2(["--mode", "train", "--voxforge", root, "--iters", str(iters), "--model", root + "init.txt"], outs)
+    got_n = [int(t.split("Got ")[1].split()[0]) for t in texts]
+    assert sum(got_n) == len(order) and min(got_n) >= 1, texts
+    assert open(outs[0]).read() == open(outs[1]).read()          # every rank ends with the identical model
+    for tag, ref in (("mean", rm), ("var", rv)):
+        g2 = nums(outs[0], tag)
+        assert np.array_equal(np.isnan(g2), np.isnan(ref))
+        np.testing.assert_allclose(g2[ok], ref[ok], rtol=1e-7, atol=1e-9)     # the single-process oracle
+    np.testing.assert_allclose(nums(outs[0], "mean")[ok], gm[ok], rtol=1e-9, atol=1e-12)   # and the one-rank run of the driver
+    outs = [root + "rand_r0.txt", root + "rand_r1.txt"]
+    launch2(["--mode", "train", "--voxforge", root, "--iters", "1"], outs)
+    assert open(outs[0]).read() == open(outs[1]).read()
+    for tag in ("mean", "var"):
+        a1, a2 = nums(root + "rand.txt", tag), nums(outs[0], tag)
+        m_ = ~np.isnan(a1)
+        assert np.array_equal(np.isnan(a1), np.isnan(a2))
+        np.testing.assert_allclose(a2[m_], a1[m_], rtol=1e-6, atol=1e-8)      # same seed, same jitter; sums added in another order
     # ---- ALIGN mode under the initial model ----
     out = _run([SRX, "--mode", "align", "--voxforge", root, "--model", root + "init.txt"], env)
     rows = [ln.split() for ln in out.splitlines() if ln and ln[0].isdigit()]
@@ -277,3 +323,32 @@ def test_headless_driver_prompts_through_the_lexicon(tmp_path):
     m1, m2 = nums(root + "m.txt"), nums(root + "m2.txt")
     assert m1.size == 40 * 26 and np.isfinite(m1).sum() >= 26 * 10
     np.testing.assert_allclose(m2, m1, rtol=1e-9, equal_nan=True)   # summation order inside the device sums is not fixed
+
+
+def test_comm_rccl_single_rank_and_noop(ctx):
+    """srx_comm_* through the C ABI: the world-1 communicator is a no-op; with SRX_COMM_FORCE_RCCL=1 a ONE-rank RCCL
+    communicator is built from srx_comm_unique_id and the three all-reduces run through ncclAllReduce on the context's
+    stream (identity on one rank: what is checked is the library lookup, the ABI and the stream ordering with the
+    kernels around them -- two ranks on one GPU are refused by RCCL, tools/probe/rccl_same_device.py)."""
+    from speechrecognition_amd import host
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(100_003)
+    c0 = host.Comm(ctx)
+    d = ctx.array(a)
+    c0.allreduce_sum_f64(d)
+    assert c0.bytes_reduced() == 0 and np.array_equal(d.get(), a)
+    c0.close()
+    os.environ["SRX_COMM_FORCE_RCCL"] = "1"
+    try:
+        c1 = host.Comm(ctx, 0, 1, host.Comm.unique_id())
+    finally:
+        del os.environ["SRX_COMM_FORCE_RCCL"]
+    f = ctx.array(a.astype(np.float32))
+    i = ctx.array(np.arange(1000, dtype=np.int32))
+    c1.allreduce_sum_f64(d)
+    c1.allreduce_max_f32(f)
+    c1.allreduce_sum_i32(i)
+    ctx.sync()
+    assert np.array_equal(d.get(), a) and np.array_equal(f.get(), a.astype(np.float32)) and np.array_equal(i.get(), np.arange(1000))
+    assert c1.bytes_reduced() == 100_003 * 12 + 4000
+    c1.close()
