@@ -240,6 +240,14 @@ void srx_align_plan_destroy(srx_align_plan *plan);
 int64_t srx_align_plan_emission_count(const srx_align_plan *plan);             /* floats: off[n_utt] */
 int srx_align_plan_emission_offsets(const srx_align_plan *plan, int64_t *off); /* host copy, [n_utt+1] */
 const int64_t *srx_align_plan_emission_offsets_dev(const srx_align_plan *plan);
+/* srx_align_plan_cache_frames(plan, 1): the caller promises that the feature buffer it scores with this plan does not
+ * change between calls.  The split-f16 path then keeps the frame-side operands of the batch (320 bytes per frame at
+ * D = 39) in the plan and rebuilds them only when the feature pointer or the model's centre / scale vector changed -- the
+ * iterations of hmm::train score the same frames under a model that moves a little, so they are built once instead of
+ * inside every scoring call (no counterpart in the reference: a memory-for-time trade sized for 288 GB of HBM).  Off by
+ * default (the cache is keyed on the pointer, not on the contents); skipped by itself when device memory is short;
+ * (plan, 0) turns it off and frees it.  Scores are the same bits either way. */
+int srx_align_plan_cache_frames(srx_align_plan *plan, int on);
 int srx_gmm_score_align_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_path, const float *feats_dev, int ld,
                             const srx_hmm_batch *hmm, const srx_align_plan *plan, float *emis_dev);
 /* srx_viterbi_batch_dev on the compact emissions of srx_gmm_score_align_dev (same kernel, same bit-exactness). */

@@ -90,6 +90,7 @@ SIGNATURES = {
     "srx_align_plan_emission_count": (C.c_int64, [vp]),
     "srx_align_plan_emission_offsets": (C.c_int, [vp, vp]),
     "srx_align_plan_emission_offsets_dev": (vp, [vp]),
+    "srx_align_plan_cache_frames": (C.c_int, [vp, C.c_int]),
     "srx_gmm_score_align_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(srx_hmm_batch), vp, vp]),
     "srx_viterbi_align_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, C.c_float, vp, vp, vp]),
     "srx_train_transitions_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp]),

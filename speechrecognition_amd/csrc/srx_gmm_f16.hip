@@ -137,25 +137,58 @@ int ensure_packed16(srx_ctx *ctx, srx_model *m, int mix_mode, int KS) {
         SRX_HIP(ctx, hipMalloc(&m->packed16, bytes));
         m->packed16_bytes = bytes;
     }
-    if (!m->colstats) SRX_HIP(ctx, hipMalloc((void **)&m->colstats, 3 * (size_t)m->D * sizeof(float)));
+    const int D = m->D;
+    const bool first = !m->colstats;
+    if (first) SRX_HIP(ctx, hipMalloc((void **)&m->colstats, 6 * (size_t)D * sizeof(float)));
     if (!m->flag16) SRX_HIP(ctx, hipMalloc((void **)&m->flag16, sizeof(int)));
-    SRX_HIP(ctx, hipMemsetAsync(m->flag16, 0, sizeof(int), ctx->stream));
+    // Centre and scale of the model as it is now (candidate).  The values IN USE are kept while they still suit the model:
+    // the frame-side operands depend only on them, so a caller that scores the same frames under a model that changes a
+    // little from call to call (the iterations of hmm::train) can keep those operands (srx_gmm_f16_align.hip).  They are
+    // replaced when a scale moved by more than 2x up / 4x down, a centre by more than two scaled units, or when the
+    // coefficients no longer fit f16 with them.
     {
         SrxProf prof_(ctx, "k_colstats16");
-        hipLaunchKernelGGL(k_colstats16, dim3(m->D), dim3(256), 0, ctx->stream, m->mean, m->var, m->G * m->M, m->D, m->colstats);
+        hipLaunchKernelGGL(k_colstats16, dim3(D), dim3(256), 0, ctx->stream, m->mean, m->var, m->G * m->M, D, m->colstats + 3 * D);
     }
     SRX_LAUNCH_CHECK(ctx);
+    bool keep = false;
+    if (!first && m->colstats_epoch > 0) {
+        std::vector<float> h(6 * (size_t)D);
+        SRX_HIP(ctx, hipMemcpyAsync(h.data(), m->colstats, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        keep = true;
+        for (int d = 0; d < D && keep; d++) {
+            const float c0 = h[d], s0 = h[D + d], c1 = h[3 * D + d], s1 = h[4 * D + d];
+            keep = s1 <= 2.0f * s0 && s1 >= 0.25f * s0 && fabsf(c1 - c0) <= 2.0f * s0;   // false for NaN
+        }
+    }
+    auto adopt = [&]() -> int {
+        SRX_HIP(ctx, hipMemcpyAsync(m->colstats, m->colstats + 3 * D, 3 * (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        m->colstats_epoch++;
+        return SRX_OK;
+    };
+    if (!keep) {
+        int rc = adopt();
+        if (rc != SRX_OK) return rc;
+    }
     const int64_t n = (int64_t)ntiles_alloc * 2 * KS * 64;
-    {
-        SrxProf prof_(ctx, "k_pack16");
-        hipLaunchKernelGGL(k_pack16, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, m->mean, m->var, m->logwt, m->colstats,
-                           m->G, m->M, m->D, KS, MP, Muse, ntiles_alloc, (f16x8 *)m->packed16, m->flag16);
-    }
-    SRX_LAUNCH_CHECK(ctx);
-    // the model changed: one 4-byte read-back decides whether its coefficients fit f16
     int flag = 0;
-    SRX_HIP(ctx, hipMemcpyAsync(&flag, m->flag16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        SRX_HIP(ctx, hipMemsetAsync(m->flag16, 0, sizeof(int), ctx->stream));
+        {
+            SrxProf prof_(ctx, "k_pack16");
+            hipLaunchKernelGGL(k_pack16, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, m->mean, m->var, m->logwt, m->colstats,
+                               m->G, m->M, m->D, KS, MP, Muse, ntiles_alloc, (f16x8 *)m->packed16, m->flag16);
+        }
+        SRX_LAUNCH_CHECK(ctx);
+        // the model changed: one 4-byte read-back decides whether its coefficients fit f16
+        SRX_HIP(ctx, hipMemcpyAsync(&flag, m->flag16, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (flag == 0 || !keep) break;
+        keep = false;            // the kept values no longer fit: take the model's own and pack once more
+        int rc = adopt();
+        if (rc != SRX_OK) return rc;
+    }
     m->f16_ok = flag == 0;
     m->packed16_version = m->version;
     m->packed16_mode = mix_mode;

@@ -357,6 +357,11 @@ class HmmBatch:
             check(self.ctx.lib.srx_align_plan_emission_offsets(h, _ptr(self.emis_off)), self.ctx.h)
         return self._plan
 
+    def cache_frames(self, on=True):
+        """srx_align_plan_cache_frames: promise that the feature buffer scored with this batch's plan stays unchanged
+        (training iterations), so the frame-side operands are built once."""
+        check(self.ctx.lib.srx_align_plan_cache_frames(self.align_plan(), int(on)), self.ctx.h)
+
     def score_align(self, model, feats_d, ld, emis_d=None, mix_mode=SRX_MIX_COMPONENT0, path=None):
         """(*acm)(fv, ctx) for every frame and every state of the frame's own utterance (src/hmm.cpp:166)."""
         from ._capi import SRX_SCORE_MFMA_F16X3

@@ -955,7 +955,10 @@ void hmm::train(vector<utterance> &ut, int iterations) {
         ~PlanGuard() { srx_align_plan_destroy(p); }
     } plan;
     const bool compact = g_score_path != SRX_SCORE_MFMA;
-    if (compact) check(srx_align_plan_create(ctx, b.foff.data(), b.soff.data(), b.c.n_utt, &plan.p));
+    if (compact) {
+        check(srx_align_plan_create(ctx, b.foff.data(), b.soff.data(), b.c.n_utt, &plan.p));
+        check(srx_align_plan_cache_frames(plan.p, 1));   // d_x is fixed for all iterations: frame operands are built once
+    }
     const size_t n_emis = compact ? (size_t)srx_align_plan_emission_count(plan.p) : (size_t)T * G;
     Dev<float> d_e(n_emis ? n_emis : 1), d_final((size_t)b.c.n_utt), d_logp((size_t)T * M), d_shift((size_t)G * M);
     Dev<int32_t> d_path((size_t)T), d_status((size_t)b.c.n_utt), d_gid((size_t)T);

@@ -73,6 +73,7 @@ class TrainingShard:
         self.emissions = emissions
         if emissions == "compact":
             hmm_batch.align_plan()
+            hmm_batch.cache_frames(True)     # the shard's features are fixed for its lifetime: frame operands are built once
             self.emis = ctx.empty((max(hmm_batch.emis_count, 1),), np.float32)   # utterance blocks [T_u][S_u]
         else:
             self.emis = ctx.empty((G, max(T, 1)), np.float32)      # state-major [G][T]

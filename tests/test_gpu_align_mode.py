@@ -69,6 +69,20 @@ def test_align_scores_equal_dense_scores_bitwise(ctx, oracle, G, M, D, mode):
             o = oracle.gmm_score_shifted(feats[a:b], mean, var, lw, D)[:, tieds[u]].ravel()
             assert np.isfinite(o).all() and np.isfinite(g).all()
         assert (np.abs(g - o) <= 1e-4 * np.maximum(np.abs(o), 1.0)).all()
+    # the frame-operand cache (srx_align_plan_cache_frames): same bits, also on the second call (cache hit) and after the
+    # model changed (the cache is kept while the model's centre / scale vector is, rebuilt when it is not)
+    hb.cache_frames(True)
+    for rep in range(2):
+        assert hb.score_align(model, feats_d, 39, mix_mode=mode).get().tobytes() == got.tobytes(), rep
+    model.set(mean + 0.01, var * 1.02, w)                   # a small move: centre / scale are kept, operands reused
+    moved = hb.score_align(model, feats_d, 39, mix_mode=mode).get()
+    assert moved.tobytes() == _compact_from_dense(model.score(feats, mode, SRX_SCORE_MFMA_F16X3), hb, tieds).tobytes()
+    model.set(mean * 40.0 + 7.0, var * 900.0, w)           # a large move: new centre / scale, operands rebuilt
+    moved = hb.score_align(model, feats_d, 39, mix_mode=mode).get()
+    assert moved.tobytes() == _compact_from_dense(model.score(feats, mode, SRX_SCORE_MFMA_F16X3), hb, tieds).tobytes()
+    hb.cache_frames(False)
+    model.set(mean, var, w)
+    assert hb.score_align(model, feats_d, 39, mix_mode=mode).get().tobytes() == got.tobytes()
     # exact path in the compact layout
     ex = hb.score_align(model, feats_d, 39, mix_mode=mode, path=SRX_SCORE_EXACT).get()
     exd = _compact_from_dense(model.score(feats, mode, SRX_SCORE_EXACT), hb, tieds)
