@@ -4,13 +4,43 @@
 // Replaces the same reference loops as k_em_accum (hmm::train passes, src/hmm.cpp:298-339).  Frames are sorted by
 // tied state once per iteration (stable radix sort: within a state they stay in frame order, so sums are
 // deterministic -- no atomics anywhere); a workgroup then owns up to CH consecutive frames of ONE state and keeps
-// that state's M x (1+D) sums in registers while the frames' zetas and feature rows pass through LDS; states with
-// more than CH frames are split and their partial sums added in chunk order by a second small kernel.
+// that state's M x D sums in registers while the frames' zetas and feature rows pass through LDS (pass 2: the squared
+// f32 difference to the new mean depends on component AND column, so it is no matrix product; an LDS-free form with
+// one wave per item and 128-bit row loads was measured at 10.8 ms against this form's 9.1 -- the f64 <-> f32 conversions
+// it repeats per component cost more than the LDS reads it saves).  Pass 1 IS a matrix product per state and runs on
+// the f64 matrix cores (k_em_accum1_mfma).  States with more than CH frames are split and their partial sums added in
+// chunk order by a second small kernel.
 // At G = 2000, M = 16, D = 39 the HBM-atomics form spends 157 ms per pass on 5e6 frames; this form is bound by
 // reading logp and the feature rows once.
 #include <hipcub/hipcub.hpp>
 
 #include "srx_common.h"
+
+// exp(y) in f64 for the zeta of the accumulation passes (y = logp - shift: at most a little above 0, down to -inf).
+// n = rint(y / ln 2), r = y - n ln 2 in two parts, degree-13 Taylor polynomial on |r| <= 0.347 (remainder 4e-18),
+// v_ldexp_f64 for the scale (gradual underflow like exp()).  18 f64 instructions, no branches; measured against the
+// oracle through the statistics at rtol 1e-9.  NaN stays NaN; below -745.2 the result is 0.
+__device__ __forceinline__ double srx_exp_f64(double y) {
+    const double n = rint(y * 1.4426950408889634);
+    double r = fma(-n, 6.93147180369123816490e-01, y);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;               // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);             // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);            // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);            // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);           // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);             // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);            // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);            // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);            // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);           // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);           // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = ldexp(p, (int)n);
+    return y < -745.2 ? 0.0 : v;                     // (also y = -inf, where r is NaN)
+}
 
 static constexpr int CH = 2048;     // frames per work item
 static constexpr int FB = 32;       // frames staged per step
@@ -78,20 +108,22 @@ __global__ __launch_bounds__(1024) void k_em_item_scan(const int64_t *__restrict
     if (threadIdx.x == 1023) item_start[G] = part[1023];
 }
 
-// One work item = up to CH frames of one state.  PASS 1: sums [zeta, zeta*x_d]; PASS 2: [zeta*diff_d^2],
-// diff = f32(x_d - meanB[o][d]) (src/hmm.cpp:331).  partial[item][M*stride].
-// Thread = (component m = tid / 16, column dq = tid % 16) with the row elements e = dq, dq + 16, dq + 32, dq + 48 of
-// that component in registers: one zeta read serves all of a thread's sums, the staged values are already f64, and
-// the frame loop is unrolled.  Sums run in frame order, one fused multiply-add per term (f64; the reference sums in
-// 80-bit long double, src/hmm.cpp:285-334).
-template <int PASS, int NACC>
-__global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
-                                                      const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
-                                                      int M, int D, const float *__restrict__ weight, const float *__restrict__ logp,
-                                                      const float *__restrict__ shift, const double *__restrict__ meanB,
-                                                      double *__restrict__ partial) {
+// PASS 2: one work item = up to CH frames of one state, sums [zeta * diff_d^2], diff = f32(x_d - meanB[o][d])
+// (src/hmm.cpp:331).  partial[item][M*D].
+// Thread = (frame parity h = tid / 128, component pair mp = (tid / 16) % 8 -> components mp and mp + 8, column dq = tid % 16)
+// with the row elements e = dq, dq + 16, dq + 32, dq + 48 of both components in registers: per frame of its parity a thread
+// reads two zetas and NACC staged values from LDS for 2 * NACC sums (the kernel is bound by those LDS reads: one component
+// per thread needed 1 + NACC reads for NACC sums).  The staged values are already f64 and the frame loop is unrolled.  Sums
+// run in frame order within a parity, one fused multiply-add per term (f64; the reference sums in 80-bit long double,
+// src/hmm.cpp:319-334); the two parities are added at the end.
+template <int NACC>
+__global__ __launch_bounds__(256) void k_em_accum_seg2(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
+                                                       const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
+                                                       int M, int D, const float *__restrict__ weight, const float *__restrict__ logp,
+                                                       const float *__restrict__ shift, const double *__restrict__ meanB,
+                                                       double *__restrict__ partial) {
     __shared__ double zeta[FB][16];
-    __shared__ double xv[FB][65];   // PASS 1: [1, x_0 .. x_{D-1}]; PASS 2: [x_0 .. x_{D-1}]
+    __shared__ double xv[FB][65];
     __shared__ int ft[2][FB];
     const int item = blockIdx.x;
     if (item >= item_start[G]) return;
@@ -103,24 +135,26 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
     const int g = lo;
     const int64_t p0 = start[g] + (int64_t)(item - item_start[g]) * CH;
     const int64_t p1 = p0 + CH < start[g + 1] ? p0 + CH : start[g + 1];
-    const int stride = PASS == 1 ? 1 + D : D;
+    const int stride = D;
     const int R = M * stride;
-    const int m = threadIdx.x >> 4, dq = threadIdx.x & 15;
-    double acc[NACC], mb[NACC];
-    bool live[NACC];   // NACC = ceil(stride / 16): only the last accumulator can be past the row's end
+    const int h = threadIdx.x >> 7, mp = (threadIdx.x >> 4) & 7, dq = threadIdx.x & 15;
+    double acc[2][NACC], mb[2][NACC];
+    bool live[2][NACC];   // NACC = ceil(D / 16): only the last accumulator can be past the row's end
 #pragma unroll
-    for (int a = 0; a < NACC; a++) {
-        const int e = dq + 16 * a;
-        acc[a] = 0.0;
-        live[a] = m < M && e < stride;
-        mb[a] = (PASS == 2 && live[a]) ? meanB[((size_t)g * M + m) * D + e] : 0.0;
-    }
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int a = 0; a < NACC; a++) {
+            const int m = mp + 8 * c, e = dq + 16 * a;
+            acc[c][a] = 0.0;
+            live[c][a] = m < M && e < stride;
+            mb[c][a] = live[c][a] ? meanB[((size_t)g * M + m) * D + e] : 0.0;
+        }
     for (int i = threadIdx.x; i < FB * 16; i += 256) (&zeta[0][0])[i] = 0.0;   // components >= M and the tail frames stay 0
     // The step's inputs are gathered one step ahead into registers (each thread's share of the FB x M log-densities
-    // and the FB x stride feature values), so their latency passes under the previous step's sums instead of in
+    // and the FB x D feature values), so their latency passes under the previous step's sums instead of in
     // front of a barrier; the frame indices run one step further ahead still (register, then LDS).
     constexpr int NZ = 2;   // FB * M / 256 with M <= 16
-    constexpr int NX = 8;   // FB * stride / 256 with stride <= 64
+    constexpr int NX = 8;   // FB * D / 256 with D <= 64
     float zr[NZ], xr[NX];
     double zw[NZ], zs[NZ];  // weight and shift of the components this thread stages
 #pragma unroll
@@ -141,9 +175,7 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
         for (int k = 0; k < NX; k++) {
             const int i = threadIdx.x + 256 * k;
             const int f = i / stride, e = i - f * stride;
-            float v = 0.0f;
-            if (i < FB * stride && f < nf && !(PASS == 1 && e == 0)) v = feats[(int64_t)ft[buf][f] * ld + (PASS == 1 ? e - 1 : e)];
-            xr[k] = v;
+            xr[k] = (i < FB * stride && f < nf) ? feats[(int64_t)ft[buf][f] * ld + e] : 0.0f;
         }
     };
     const int64_t nsteps = (p1 - p0 + FB - 1) / FB;
@@ -160,14 +192,14 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
         for (int k = 0; k < NZ; k++) {
             const int i = threadIdx.x + 256 * k;
             const int f = i / M, mm = i - f * M;
-            // zeta = weight * prob (src/hmm.cpp:282,307,328), shifted; frames past the item's end contribute 0
-            if (i < FB * M) zeta[f][mm] = f < nf ? zw[k] * exp((double)zr[k] - zs[k]) : 0.0;
+            // zeta = weight * prob (src/hmm.cpp:328), shifted; frames past the item's end contribute 0
+            if (i < FB * M) zeta[f][mm] = f < nf ? zw[k] * srx_exp_f64((double)zr[k] - zs[k]) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < NX; k++) {
             const int i = threadIdx.x + 256 * k;
             const int f = i / stride, e = i - f * stride;
-            if (i < FB * stride) xv[f][e] = f < nf ? ((PASS == 1 && e == 0) ? 1.0 : (double)xr[k]) : 0.0;
+            if (i < FB * stride) xv[f][e] = f < nf ? (double)xr[k] : 0.0;
         }
         if (threadIdx.x < frames_of(st + 1)) ft[(st + 1) & 1][threadIdx.x] = ord;
         __syncthreads();
@@ -176,24 +208,134 @@ __global__ __launch_bounds__(256) void k_em_accum_seg(const float *__restrict__ 
             if (threadIdx.x < frames_of(st + 2)) ord = order[p0 + (st + 2) * FB + threadIdx.x];
         }
 #pragma unroll 8
-        for (int f = 0; f < FB; f++) {
-            const double z = zeta[f][m];
+        for (int f2 = 0; f2 < FB / 2; f2++) {
+            const int f = 2 * f2 + h;
+            const double z0 = zeta[f][mp], z1 = zeta[f][mp + 8];
 #pragma unroll
             for (int a = 0; a < NACC; a++) {
-                // no test on live[a] here: a dead accumulator sums staged garbage that is never stored
+                // no test on live[][] here: a dead accumulator sums staged garbage that is never stored
                 const double x = xv[f][dq + 16 * a];
-                if (PASS == 1) {
-                    acc[a] = fma(z, x, acc[a]);
-                } else {
-                    const float diff = (float)(x - mb[a]);
-                    acc[a] = fma(z * (double)diff, (double)diff, acc[a]);
-                }
+                // (rounding the difference to 24 bits with f64 arithmetic -- Veltkamp's split, three operations -- instead of
+                //  the two conversions was measured slower: 9.9 ms against 8.6 per 5e7 frames)
+                const float d0 = (float)(x - mb[0][a]), d1 = (float)(x - mb[1][a]);
+                acc[0][a] = fma(z0 * (double)d0, (double)d0, acc[0][a]);
+                acc[1][a] = fma(z1 * (double)d1, (double)d1, acc[1][a]);
             }
         }
     }
+    // odd-frame sums onto the even-frame ones (through the staging array: 128 threads x 2 x NACC <= FB x 65 doubles)
+    __syncthreads();
+    double *comb = &xv[0][0];
+    if (h == 1) {
 #pragma unroll
-    for (int a = 0; a < NACC; a++)
-        if (live[a]) partial[(size_t)item * R + m * stride + dq + 16 * a] = acc[a];
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int a = 0; a < NACC; a++) comb[((threadIdx.x & 127) * 2 + c) * NACC + a] = acc[c][a];
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int a = 0; a < NACC; a++)
+                if (live[c][a])
+                    partial[(size_t)item * R + (mp + 8 * c) * stride + dq + 16 * a] = acc[c][a] + comb[(threadIdx.x * 2 + c) * NACC + a];
+    }
+}
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// PASS 1 on the f64 matrix cores: stats1[g][m][e] = sum_t zeta[t][m] * xx[t][e], xx = [1, x_0 .. x_{D-1}], is a
+// [M x T_g] . [T_g x (1+D)] product per state.  One wave per work item (<= CH frames of one state); per group of four
+// frames one v_mfma_f64_16x16x4_f64 per 16 columns: A = zeta^T (lane l holds zeta of frame l>>4, component l&15 -- each
+// (frame, component) exponential is computed exactly once, by the lane that feeds it), B = xx (lane l holds column
+// 16c + (l&15) of frame l>>4, straight from the feature row).  No LDS, no barrier: the LDS form spent its time
+// re-reading zeta and x from LDS for every fused multiply-add (6.9 ms per 5e7 frames against 1.2 ms of f64 matrix time).
+// Order indices run two 32-frame blocks ahead of the sums and the log-densities / feature values one block ahead.
+template <int NCT>
+__global__ __launch_bounds__(64) void k_em_accum1_mfma(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
+                                                       const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G,
+                                                       int M, int D, const float *__restrict__ weight, const float *__restrict__ logp,
+                                                       const float *__restrict__ shift, double *__restrict__ partial) {
+    const int item = blockIdx.x;
+    if (item >= item_start[G]) return;
+    int lo = 0, hi = G;   // item_start[lo] <= item < item_start[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int g = lo;
+    const int64_t p0 = start[g] + (int64_t)(item - item_start[g]) * CH;
+    const int64_t p1 = p0 + CH < start[g + 1] ? p0 + CH : start[g + 1];
+    const int lane = threadIdx.x, m = lane & 15, k = lane >> 4;
+    const int stride = 1 + D, R = M * stride;
+    const double wm = m < M ? (double)weight[(size_t)g * M + m] : 0.0;
+    const double sm = m < M ? (double)shift[(size_t)g * M + m] : 0.0;
+    constexpr int GB = 8;                       // groups of four frames per block
+    f64x4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; c++) acc[c] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int64_t nb = (p1 - p0 + 4 * GB - 1) / (4 * GB);
+    auto load_ord = [&](int64_t b, int (&o)[GB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < GB; j++) {
+            const int64_t pos = p0 + (b * GB + j) * 4 + k;
+            o[j] = pos < p1 ? order[pos] : -1;
+        }
+    };
+    auto load_data = [&](const int (&o)[GB], float (&lp)[GB], float (&x)[GB][NCT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < GB; j++) {
+            const bool v = o[j] >= 0;
+            const int64_t t = v ? o[j] : 0;
+            lp[j] = (v && m < M) ? logp[t * M + m] : -__builtin_huge_valf();   // -inf: zeta = 0
+#pragma unroll
+            for (int c = 0; c < NCT; c++) {
+                const int e = c * 16 + m;          // column of xx
+                float xv = 0.0f;
+                if (v && e >= 1 && e <= D) xv = feats[t * ld + e - 1];
+                if (v && e == 0) xv = 1.0f;
+                x[j][c] = xv;
+            }
+        }
+    };
+    int o_a[GB], o_b[GB];
+    float lp_a[GB], lp_b[GB], x_a[GB][NCT], x_b[GB][NCT];
+    load_ord(0, o_a);
+    load_data(o_a, lp_a, x_a);
+    load_ord(1, o_b);
+    auto compute = [&](const float (&lp)[GB], const float (&x)[GB][NCT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < GB; j++) {
+            // zeta = weight * prob (src/hmm.cpp:282,307), shifted; a frame past the item's end has logp = -inf -> 0
+            const double z = wm * srx_exp_f64((double)lp[j] - sm);
+#pragma unroll
+            for (int c = 0; c < NCT; c++) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(z, (double)x[j][c], acc[c], 0, 0, 0);
+        }
+    };
+    for (int64_t b = 0; b < nb; b += 2) {
+        // block b: data in (lp_a, x_a); order of block b+1 in o_b
+        if (b + 1 < nb) {
+            load_data(o_b, lp_b, x_b);
+            load_ord(b + 2, o_a);
+        }
+        compute(lp_a, x_a);
+        if (b + 1 < nb) {
+            if (b + 2 < nb) {
+                load_data(o_a, lp_a, x_a);
+                load_ord(b + 3, o_b);
+            }
+            compute(lp_b, x_b);
+        }
+    }
+    // C/D of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int c = 0; c < NCT; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = k + 4 * r, e = c * 16 + m;
+            if (row < M && e < stride) partial[(size_t)item * R + row * stride + e] = acc[c][r];
+        }
 }
 
 // Log-densities of the aligned frames under A in sorted order: a work item's state parameters sit in LDS and the item's
@@ -411,10 +553,16 @@ int srx_em_accum_seg(srx_ctx *ctx, const float *feats, int ld, const int32_t *gi
     void *pw = nullptr;
     int rc = srx_workspace(ctx, 3, (size_t)max_items * R * sizeof(double), &pw);
     if (rc != SRX_OK) return rc;
-    {
-        SrxProf prof_(ctx, PASS == 1 ? "k_em_accum_seg1" : "k_em_accum_seg2");
-        const int nacc = ((PASS == 1 ? 1 + D : D) + 15) / 16;
-        auto kern = nacc <= 1 ? k_em_accum_seg<PASS, 1> : nacc == 2 ? k_em_accum_seg<PASS, 2> : nacc == 3 ? k_em_accum_seg<PASS, 3> : k_em_accum_seg<PASS, 4>;
+    if (PASS == 1) {
+        SrxProf prof_(ctx, "k_em_accum_seg1");
+        const int nct = (1 + D + 15) / 16;
+        auto kern = nct <= 1 ? k_em_accum1_mfma<1> : nct == 2 ? k_em_accum1_mfma<2> : nct == 3 ? k_em_accum1_mfma<3> : k_em_accum1_mfma<4>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)max_items), dim3(64), 0, ctx->stream, feats, ld, v.order, v.start, v.item_start, G, M, D,
+                           weight, logp, shift, (double *)pw);
+    } else {
+        SrxProf prof_(ctx, "k_em_accum_seg2");
+        const int nacc = (D + 15) / 16;
+        auto kern = nacc <= 1 ? k_em_accum_seg2<1> : nacc == 2 ? k_em_accum_seg2<2> : nacc == 3 ? k_em_accum_seg2<3> : k_em_accum_seg2<4>;
         hipLaunchKernelGGL(kern, dim3((unsigned)max_items), dim3(256), 0, ctx->stream, feats, ld, v.order, v.start,
                            v.item_start, G, M, D, weight, logp, shift, meanB, (double *)pw);
     }
