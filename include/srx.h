@@ -254,6 +254,40 @@ int srx_gmm_score_align_dev(srx_ctx *ctx, srx_model *m, int mix_mode, int score_
 int srx_viterbi_align_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const srx_align_plan *plan, const float *emis_dev,
                           float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
 
+/* ---------------------------------------------------------------- lexicon HMM / decoding */
+/* hmm::hmm(pronlex&, unigram_model&, acoustic_model*, state_model*)  src/hmm.cpp:92-129 (USE_SUBPHONES false): host helper.
+ * Words in the iteration order of the reference's map<string, pronlist> (sorted by spelling); word w has the phones
+ * phones[phone_off[w] .. phone_off[w+1]) (its first pronunciation) and the unigram log-probability uni_logp[w]
+ * (unigram_model::get, src/langmodel.cpp:21-27); its start transition carries lmsf * uni_logp[w] (LMSF = 5,
+ * src/hmm.hpp:33).  State 0 is the start state; then per word its phone states and a terminating silence.
+ * Outputs (CSR, transitions in the reference's push_back order): tr_off[n_states+1], tr_tgt / tr_logp[n_tr],
+ * ctx[n_states][3] = (prev, curr, next) phone, word_of[n_states] (-1 for the start state).  With tr_off == NULL only the
+ * two counts are written. */
+int srx_hmm_build_lexicon(int n_words, const int32_t *phone_off, const int32_t *phones, const float *uni_logp, float lmsf,
+                          int32_t *tr_off, int32_t *tr_tgt, float *tr_logp, int32_t *ctx, int32_t *word_of, int64_t *n_states,
+                          int64_t *n_tr);
+
+/* An HMM with an arbitrary transition list on the device (host arrays in; tied[s] = emission column of state s).
+ * srx_decode_plan_set_transitions replaces the log-probabilities after hmm::update_states (src/hmm.cpp:361-366). */
+typedef struct srx_decode_plan srx_decode_plan;
+int srx_decode_plan_create(srx_ctx *ctx, int n_states, const int32_t *tr_off, const int32_t *tr_tgt, const float *tr_logp,
+                           const int32_t *tied, srx_decode_plan **out);
+int srx_decode_plan_set_transitions(srx_decode_plan *plan, const float *tr_logp);
+void srx_decode_plan_destroy(srx_decode_plan *plan);
+
+/* hmm::viterbi  src/hmm.cpp:150-224 on that HMM, for every utterance of a batch (frame_off: HOST array [n_utt+1], frames
+ * counted over the emission matrix as in srx_viterbi_batch_dev): beam search with `beam_width` (src/hmm.cpp:165), `logp`
+ * carried across a source's transitions as the reference has it (src/hmm.cpp:164-169), exact ties to the higher source
+ * index.  final_mode 0: the path must end in the last state, as the reference is compiled (src/hmm.cpp:210-215);
+ * final_mode 1: it ends in the best active state above -1e10f, the recognition variant the reference has commented out
+ * (src/hmm.cpp:196-209; its `throw 1729` is status 1 here).  Outputs: path[frames] (state indices), final_logp[n_utt],
+ * final_state[n_utt] (may be NULL), status[n_utt] (0 ok, 1 NO PATH).  Score and path are bit-identical to the CPU
+ * restatement (PARITY UNPINNED: the reference never runs Viterbi on its lexicon HMM).  Back-pointers take
+ * 4 * frames * n_states bytes of the context's workspace. */
+int srx_viterbi_graph_dev(srx_ctx *ctx, const srx_decode_plan *plan, const float *emis_dev, int64_t stride_t, int64_t stride_g,
+                          const int64_t *frame_off, int n_utt, float beam_width, int final_mode, int32_t *path_dev,
+                          float *final_logp_dev, int32_t *final_state_dev, int32_t *status_dev);
+
 /* hmm::train_transition_probabilities  src/hmm.cpp:229-243 (+ set/get_adv_prob :26-35) for every
  * utterance whose status is 0. */
 int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,

@@ -64,6 +64,13 @@ def lib():
         L.orc_em_statistics.argtypes = [f32p, C.c_int, C.c_long, i32p, C.c_int, C.c_int, C.c_int,
                                         ldp, ldp, f32p, f32p, ldp, ldp, f32p, f32p, ldp, C.c_float]
         L.orc_state_model.argtypes = [i32p, f32p, C.c_long, C.c_int, f32p, i32p]
+        L.orc_build_lexicon_hmm.restype = C.c_long
+        L.orc_build_lexicon_hmm.argtypes = [C.c_int, i32p, i32p, f32p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.POINTER(C.c_long)]
+        L.orc_viterbi_graph.restype = C.c_int
+        L.orc_viterbi_graph.argtypes = [f32p, C.c_long, i32p, C.c_long, C.c_int, i32p, i32p, f32p, C.c_float, C.c_int, C.c_int,
+                                        i32p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_long)]
+        L.orc_update_states.argtypes = [C.c_int, i32p, f32p, i32p, f32p, i32p]
         L.orc_pipeline_utterance.restype = C.c_long
         L.orc_pipeline_utterance.argtypes = [f32p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                              C.c_int, C.c_int, C.c_int, C.c_int, ldp, ldp, f32p, C.c_int, i32p, C.c_int,
@@ -211,6 +218,49 @@ def state_model(cls, adv, C_):
     cnt = np.zeros(C_, np.int32)
     lib().orc_state_model(cls, adv, len(cls), C_, ps, cnt)
     return ps, cnt
+
+
+def build_lexicon_hmm(word_phones, uni_logp, lmsf=5.0):
+    """hmm::hmm(pronlex&, unigram_model&, ...)  src/hmm.cpp:92-129.  word_phones: list of int arrays in the map's
+    (sorted-by-spelling) order.  Returns dict(n_states, tr_off, tr_tgt, tr_logp, ctx [n,3], word_of)."""
+    n = len(word_phones)
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(p) for p in word_phones])
+    ph = np.ascontiguousarray(np.concatenate(word_phones) if n else np.zeros(0), dtype=np.int32)
+    if len(ph) == 0:
+        ph = np.zeros(1, np.int32)
+    lp = np.ascontiguousarray(uni_logp, dtype=np.float32)
+    ntr = C.c_long(0)
+    ns = lib().orc_build_lexicon_hmm(n, off, ph, lp, lmsf, None, None, None, None, None, C.byref(ntr))
+    tr_off = np.zeros(ns + 1, np.int32)
+    tr_tgt = np.zeros(ntr.value, np.int32)
+    tr_logp = np.zeros(ntr.value, np.float32)
+    ctx = np.zeros((ns, 3), np.int32)
+    word_of = np.zeros(ns, np.int32)
+    lib().orc_build_lexicon_hmm(n, off, ph, lp, lmsf, tr_off.ctypes.data, tr_tgt.ctypes.data, tr_logp.ctypes.data, ctx.ctypes.data,
+                                word_of.ctypes.data, C.byref(ntr))
+    return dict(n_states=int(ns), tr_off=tr_off, tr_tgt=tr_tgt, tr_logp=tr_logp, ctx=ctx, word_of=word_of)
+
+
+def viterbi_graph(emis, tied, tr_off, tr_tgt, tr_logp, beam=1e10, order=0, final_mode=0):
+    """hmm::viterbi on an arbitrary transition list.  Returns dict(status, path, final, final_state, nties)."""
+    emis = np.ascontiguousarray(emis, dtype=np.float32)
+    T, ldE = emis.shape
+    n = len(tr_off) - 1
+    path = np.full(T, -1, np.int32)
+    final, fstate, nties = C.c_float(0), C.c_int(-1), C.c_long(0)
+    rc = lib().orc_viterbi_graph(emis, ldE, np.ascontiguousarray(tied, np.int32), T, n, np.ascontiguousarray(tr_off, np.int32),
+                                 np.ascontiguousarray(tr_tgt, np.int32), np.ascontiguousarray(tr_logp, np.float32), beam, order,
+                                 final_mode, path, C.byref(final), C.byref(fstate), C.byref(nties))
+    return dict(status=rc, path=path, final=np.float32(final.value), final_state=int(fstate.value), nties=int(nties.value))
+
+
+def update_states(tr_off, tr_logp, cls, probsum, count):
+    """hmm::update_states  src/hmm.cpp:361-366; returns the new transition log-probs."""
+    tr = np.ascontiguousarray(tr_logp, np.float32).copy()
+    lib().orc_update_states(len(tr_off) - 1, np.ascontiguousarray(tr_off, np.int32), tr, np.ascontiguousarray(cls, np.int32),
+                            np.ascontiguousarray(probsum, np.float32), np.ascontiguousarray(count, np.int32))
+    return tr
 
 
 def em_statistics(feats, gid, D, A_mean, A_var, A_weight, blend_keep=0.2):

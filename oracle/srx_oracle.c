@@ -541,3 +541,152 @@ long orc_pipeline_utterance(float *x, long L, int wl, int hop, const orc_filter 
     (void)G;
     return n;
 }
+
+/* ------------------------------------------------------------------------------------
+ * General-topology HMMs: the lexicon HMM and hmm::viterbi on it  (src/hmm.cpp:92-129, 150-224)
+ * PARITY UNPINNED: main() never calls viterbi on the lexicon HMM, the selection of the best final
+ * state is commented out in the reference (src/hmm.cpp:196-209) and no output of it exists.
+ * ---------------------------------------------------------------------------------- */
+
+/* hmm::hmm(pronlex&, unigram_model&, acoustic_model*, state_model*)  src/hmm.cpp:92-129, USE_SUBPHONES=false.
+ * Words in the iteration order of the reference's map<string, pronlist> (sorted by spelling); word w has phones
+ * phones[phone_off[w] .. phone_off[w+1]) (pronunciations[0]) and unigram log-probability uni_logp[w]
+ * (unigram_model::get, src/langmodel.cpp:21-27); the start transition carries lmsf * uni_logp[w] (LMSF = 5, src/hmm.hpp:33).
+ * State 0 is the start state (ctx SIL,SIL,SIL from hmm_state::hmm_state, src/hmm.cpp:13-15); then per word its phone
+ * states and a terminating silence.  Outputs: tr_off[n_states+1], tr_tgt/tr_logp[n_tr] (CSR, transitions in push_back
+ * order), ctx[n_states][3], word_of[n_states] (-1 for state 0).  Returns n_states; counts only when tr_off == NULL. */
+long orc_build_lexicon_hmm(int n_words, const int *phone_off, const int *phones, const float *uni_logp, float lmsf,
+                           int *tr_off, int *tr_tgt, float *tr_logp, int *ctx, int *word_of, long *n_tr_out) {
+    long n_states = 1, n_tr = n_words;
+    for (int w = 0; w < n_words; w++) {
+        int len = phone_off[w + 1] - phone_off[w];
+        n_states += len + 1;
+        n_tr += 2 * len + 1 + 2;   /* 2 per phone state, +1 for the last one's return, 2 for the silence */
+    }
+    if (n_tr_out) *n_tr_out = n_tr;
+    if (!tr_off) return n_states;
+    /* state 0's transitions first (one per word, in word order), then the states in index order */
+    int *first = (int *)malloc(sizeof(int) * (size_t)(n_words > 0 ? n_words : 1));
+    long s = 1;
+    for (int w = 0; w < n_words; w++) { first[w] = (int)s; s += phone_off[w + 1] - phone_off[w] + 1; }
+    long q = 0;
+    tr_off[0] = 0;
+    for (int w = 0; w < n_words; w++) { tr_tgt[q] = first[w]; tr_logp[q] = lmsf * uni_logp[w]; q++; }
+    ctx[0] = ctx[1] = ctx[2] = 0;
+    word_of[0] = -1;
+    for (int w = 0; w < n_words; w++) {
+        const int *p = phones + phone_off[w];
+        int len = phone_off[w + 1] - phone_off[w];
+        int s0 = first[w], e = s0 + len;           /* e = terminating silence */
+        for (int i = s0; i < e; i++) {
+            int last = i == e - 1;
+            tr_off[i] = (int)q;
+            tr_tgt[q] = i;     tr_logp[q] = last ? ORC_LOG_THIRD : ORC_LOG_HALF; q++;
+            tr_tgt[q] = i + 1; tr_logp[q] = last ? ORC_LOG_THIRD : ORC_LOG_HALF; q++;
+            if (last) { tr_tgt[q] = 0; tr_logp[q] = ORC_LOG_THIRD; q++; }
+            ctx[i * 3 + 0] = i == s0 ? 0 : p[i - s0 - 1];
+            ctx[i * 3 + 1] = p[i - s0];
+            ctx[i * 3 + 2] = i + 1 == e ? 0 : p[i - s0 + 1];
+            word_of[i] = w;
+        }
+        tr_off[e] = (int)q;
+        tr_tgt[q] = e; tr_logp[q] = ORC_LOG_HALF; q++;
+        tr_tgt[q] = 0; tr_logp[q] = ORC_LOG_HALF; q++;
+        ctx[e * 3 + 0] = len > 0 ? p[len - 1] : 0;   /* states[e-1].ph.first (the start state's SIL for an empty word) */
+        ctx[e * 3 + 1] = 0;
+        ctx[e * 3 + 2] = 0;
+        word_of[e] = w;
+    }
+    tr_off[n_states] = (int)q;
+    free(first);
+    return n_states;
+}
+
+/* hmm::viterbi  src/hmm.cpp:150-224 on an arbitrary transition list (CSR as above).
+ *  emis[t*ldE + tied[s]] = (*acm)(*fvs[t], states[s].ctx).
+ *  `logp` accumulates across a source's transitions exactly as written (src/hmm.cpp:164-169).
+ *  order: 0 = active sources visited in descending index, 1 = ascending (the reference: unordered_map order).
+ *  final_mode 0: the path must end in the last state (src/hmm.cpp:210-215, as compiled);
+ *  final_mode 1: the commented-out recognition variant (src/hmm.cpp:196-209): best = the active state with the largest
+ *                value > -1e10f, visited in `order` with strict >; none -> status 1 (the reference would `throw 1729`).
+ *  Returns 0 ok, 1 NO PATH. */
+int orc_viterbi_graph(const float *emis, long ldE, const int *tied, long T, int n_states, const int *tr_off, const int *tr_tgt,
+                      const float *tr_logp, float beam_width, int order, int final_mode, int *path, float *final_logp,
+                      int *final_state, long *nties) {
+    float *cur = (float *)malloc(sizeof(float) * (size_t)n_states);
+    float *nxt = (float *)malloc(sizeof(float) * (size_t)n_states);
+    char *acur = (char *)calloc((size_t)n_states, 1);
+    char *anxt = (char *)calloc((size_t)n_states, 1);
+    int *back = (int *)malloc(sizeof(int) * (size_t)n_states * (size_t)(T > 0 ? T : 1));
+    long ties_seen = 0;
+    float current_best_logp = -1e10f;
+    cur[0] = 0;
+    acur[0] = 1;
+    for (long i = 0; i < T; i++) {
+        float next_best_logp = -1e10f;
+        memset(anxt, 0, (size_t)n_states);
+        for (int q = 0; q < n_states; q++) {
+            int s = order == 0 ? n_states - 1 - q : q;
+            if (!acur[s]) continue;
+            float logp = cur[s];
+            if (logp < current_best_logp - beam_width) continue;
+            for (int ti = tr_off[s]; ti < tr_off[s + 1]; ti++) {
+                int target = tr_tgt[ti];
+                logp += tr_logp[ti];
+                logp += emis[i * ldE + tied[target]];
+                if (anxt[target]) {
+                    if (logp == nxt[target]) ties_seen++;
+                    if (logp > nxt[target]) {
+                        nxt[target] = logp;
+                        next_best_logp = fmaxf(next_best_logp, logp);
+                        back[i * n_states + target] = s;
+                    }
+                } else {
+                    anxt[target] = 1;
+                    nxt[target] = logp;
+                    next_best_logp = fmaxf(next_best_logp, logp);
+                    back[i * n_states + target] = s;
+                }
+            }
+        }
+        current_best_logp = next_best_logp;
+        float *tf = cur; cur = nxt; nxt = tf;
+        char *tc = acur; acur = anxt; anxt = tc;
+    }
+    int rc = 0, best = -1;
+    if (final_mode == 0) {
+        best = n_states - 1;
+        if (!acur[best]) rc = 1;
+    } else {
+        float best_logp = -1e10f;
+        for (int q = 0; q < n_states; q++) {
+            int s = order == 0 ? n_states - 1 - q : q;
+            if (acur[s] && cur[s] > best_logp) { best_logp = cur[s]; best = s; }
+        }
+        if (best == -1) rc = 1;
+    }
+    if (rc == 0) {
+        if (final_logp) *final_logp = cur[best];
+        if (final_state) *final_state = best;
+        for (long i = T - 1; i >= 0; i--) {
+            path[i] = best;
+            best = back[i * n_states + best];
+        }
+    }
+    if (nties) *nties = ties_seen;
+    free(cur); free(nxt); free(acur); free(anxt); free(back);
+    return rc;
+}
+
+/* hmm::update_states  src/hmm.cpp:361-366 with state_model::operator()  src/hmm.cpp:39-44 on CSR transitions:
+ * every state but the start state takes the pooled advance probability of its tied class (0.5 where nothing was seen).
+ * Every lexicon state has at least two transitions (src/hmm.cpp:108-122), so set_adv_prob's tr[1] exists. */
+void orc_update_states(int n_states, const int *tr_off, float *tr_logp, const int *cls, const float *probsum, const int *count) {
+    for (int i = 1; i < n_states; i++) {
+        int c = cls[i];
+        float p = (c < 0 || count[c] == 0) ? 0.5f : probsum[c] / count[c];
+        int ntr = tr_off[i + 1] - tr_off[i];
+        if (ntr < 2) continue;   /* the reference would write tr[1] out of bounds */
+        set_adv_prob(ntr, tr_logp + tr_off[i], p);
+    }
+}

@@ -93,6 +93,11 @@ SIGNATURES = {
     "srx_align_plan_cache_frames": (C.c_int, [vp, C.c_int]),
     "srx_gmm_score_align_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(srx_hmm_batch), vp, vp]),
     "srx_viterbi_align_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, C.c_float, vp, vp, vp]),
+    "srx_hmm_build_lexicon": (C.c_int, [C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "srx_decode_plan_create": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.POINTER(vp)]),
+    "srx_decode_plan_set_transitions": (C.c_int, [vp, vp]),
+    "srx_decode_plan_destroy": (None, [vp]),
+    "srx_viterbi_graph_dev": (C.c_int, [vp, vp, vp, i64, i64, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp]),
     "srx_train_transitions_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp]),
     "srx_state_model_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, vp, C.c_int, vp, vp]),
     "srx_em_gather_gid_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, i64, vp]),

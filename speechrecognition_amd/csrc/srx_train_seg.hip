@@ -18,8 +18,8 @@
 
 // exp(y) in f64 for the zeta of the accumulation passes (y = logp - shift: at most a little above 0, down to -inf).
 // n = rint(y / ln 2), r = y - n ln 2 in two parts, degree-13 Taylor polynomial on |r| <= 0.347 (remainder 4e-18),
-// v_ldexp_f64 for the scale (gradual underflow like exp()).  18 f64 instructions, no branches; measured against the
-// oracle through the statistics at rtol 1e-9.  NaN stays NaN; below -745.2 the result is 0.
+// v_ldexp_f64 for the scale (gradual underflow like exp()).  18 f64 instructions, no branches; checked in the
+// statistics tests at rtol 1e-9 (tests/test_gpu_train.py).  NaN stays NaN; below -745.2 the result is 0.
 __device__ __forceinline__ double srx_exp_f64(double y) {
     const double n = rint(y * 1.4426950408889634);
     double r = fma(-n, 6.93147180369123816490e-01, y);

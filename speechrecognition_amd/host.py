@@ -386,6 +386,63 @@ class HmmBatch:
             self._plan = None
 
 
+# ----------------------------------------------------------------------------- lexicon HMM / decoding
+def build_lexicon_hmm(word_phones, uni_logp, lmsf=5.0):
+    """hmm::hmm(pronlex&, unigram_model&, ...)  src/hmm.cpp:92-129 -> dict(n_states, tr_off, tr_tgt, tr_logp, ctx, word_of).
+    word_phones: one int array per word, words in the order of the reference's map (sorted by spelling)."""
+    lib = _capi.load()
+    n = len(word_phones)
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(p) for p in word_phones])
+    ph = np.ascontiguousarray(np.concatenate(word_phones) if n else np.zeros(1), np.int32)
+    lp = np.ascontiguousarray(uni_logp, np.float32)
+    ns, nt = C.c_int64(0), C.c_int64(0)
+    check(lib.srx_hmm_build_lexicon(n, _ptr(off), _ptr(ph), _ptr(lp), lmsf, None, None, None, None, None, C.byref(ns), C.byref(nt)))
+    tr_off = np.zeros(ns.value + 1, np.int32)
+    tr_tgt = np.zeros(nt.value, np.int32)
+    tr_logp = np.zeros(nt.value, np.float32)
+    ctx3 = np.zeros((ns.value, 3), np.int32)
+    word_of = np.zeros(ns.value, np.int32)
+    check(lib.srx_hmm_build_lexicon(n, _ptr(off), _ptr(ph), _ptr(lp), lmsf, _ptr(tr_off), _ptr(tr_tgt), _ptr(tr_logp), _ptr(ctx3),
+                                    _ptr(word_of), C.byref(ns), C.byref(nt)))
+    return dict(n_states=int(ns.value), tr_off=tr_off, tr_tgt=tr_tgt, tr_logp=tr_logp, ctx=ctx3, word_of=word_of)
+
+
+class GraphHmm:
+    """An HMM with an arbitrary transition list on the device (srx_decode_plan) and hmm::viterbi on it."""
+
+    def __init__(self, ctx, tr_off, tr_tgt, tr_logp, tied):
+        self.ctx = ctx
+        self.n_states = len(tr_off) - 1
+        self.tr_off = np.ascontiguousarray(tr_off, np.int32)
+        self.tr_tgt = np.ascontiguousarray(tr_tgt, np.int32)
+        h = C.c_void_p()
+        check(ctx.lib.srx_decode_plan_create(ctx.h, self.n_states, _ptr(self.tr_off), _ptr(self.tr_tgt),
+                                             _ptr(np.ascontiguousarray(tr_logp, np.float32)), _ptr(np.ascontiguousarray(tied, np.int32)),
+                                             C.byref(h)), ctx.h)
+        self.h = h
+
+    def set_transitions(self, tr_logp):
+        check(self.ctx.lib.srx_decode_plan_set_transitions(self.h, _ptr(np.ascontiguousarray(tr_logp, np.float32))), self.ctx.h)
+
+    def viterbi(self, emis_d, stride_t, stride_g, frame_off, beam=1e10, final_mode=0):
+        """-> (path [frames], final [n_utt], final_state [n_utt], status [n_utt]) as host arrays."""
+        ctx = self.ctx
+        frame_off = np.ascontiguousarray(frame_off, np.int64)
+        n = len(frame_off) - 1
+        path_d = ctx.zeros((max(int(frame_off[-1]), 1),), np.int32)
+        final_d, fs_d, st_d = ctx.zeros((max(n, 1),), np.float32), ctx.zeros((max(n, 1),), np.int32), ctx.zeros((max(n, 1),), np.int32)
+        check(ctx.lib.srx_viterbi_graph_dev(ctx.h, self.h, emis_d.ptr, stride_t, stride_g, _ptr(frame_off), n, beam, final_mode,
+                                            path_d.ptr, final_d.ptr, fs_d.ptr, st_d.ptr), ctx.h)
+        ctx.sync()
+        return path_d.get(), final_d.get(), fs_d.get(), st_d.get()
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.srx_decode_plan_destroy(self.h)
+            self.h = None
+
+
 # ----------------------------------------------------------------------------- EM statistics
 def em_statistics(ctx, A, B, feats_d, ld, gid_d, T, blend_keep=0.2, allreduce_max=None, allreduce_sum=None):
     """The statistics half of one hmm::train iteration (src/hmm.cpp:274-341): rebuilds model B from the

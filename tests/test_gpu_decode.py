@@ -1,0 +1,128 @@
+"""The lexicon HMM (hmm::hmm(pronlex&, unigram_model&, ...), src/hmm.cpp:92-129) and hmm::viterbi on it (src/hmm.cpp:150-224)
+with a finite beam and both end conditions -- SURVEY.md section 8 f3.
+
+PARITY UNPINNED: the reference's main() never runs Viterbi on its lexicon HMM, the selection of the best final state is
+commented out there (src/hmm.cpp:196-209) and its unigram file is not in the repository.  The checker is the oracle's
+restatement of the same loops on an arbitrary transition list (orc_viterbi_graph), which reproduces the training-HMM
+oracle bit for bit on training topologies (tests/test_oracle_pins.py).  Bar: topology arrays identical; score bit-exact;
+path identical (the oracle visits sources in descending index, the kernel's tie rule)."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import host, synth
+
+pytestmark = pytest.mark.gpu
+
+G = 40   # NULL_CONTEXT tying: the emission column of a state is its phone
+
+
+def _lexicon(rng, n_words):
+    words = [rng.integers(1, 40, int(rng.integers(1, 7))).astype(np.int32) for _ in range(n_words)]
+    counts = rng.integers(1, 5000, n_words)
+    uni = (np.log(counts) - np.float32(np.log(counts.sum() * 3.0))).astype(np.float32)   # unigram_model::put, src/langmodel.cpp:16-19
+    return words, uni
+
+
+def _emissions_for(rng, lex, words, T_per_word, n_utt):
+    """Frames that roughly follow a random word sequence, so that paths visit many words."""
+    emis, fo = [], [0]
+    for _ in range(n_utt):
+        seq = rng.integers(0, len(words), int(rng.integers(1, 5)))
+        rows = []
+        for w in seq:
+            for ph in list(words[w]) + [0]:
+                n = int(rng.integers(2, T_per_word))
+                e = rng.standard_normal((n, G)).astype(np.float32) * 2 - 12
+                e[:, ph] += 9.0
+                rows.append(e)
+        e = np.concatenate(rows)
+        emis.append(e)
+        fo.append(fo[-1] + len(e))
+    return np.concatenate(emis), np.array(fo, np.int64)
+
+
+@pytest.mark.parametrize("n_words", [1, 10, 60, 500])
+def test_lexicon_hmm_topology_and_decode_bit_exact(ctx, oracle, n_words):
+    rng = np.random.default_rng(100 + n_words)
+    words, uni = _lexicon(rng, n_words)
+    a = host.build_lexicon_hmm(words, uni)
+    b = oracle.build_lexicon_hmm(words, uni)
+    assert a["n_states"] == b["n_states"] == 1 + sum(len(w) + 1 for w in words)
+    for k in ("tr_off", "tr_tgt", "tr_logp", "ctx", "word_of"):
+        assert a[k].tobytes() == b[k].tobytes(), k
+    # the start state fans out to every word with LMSF * unigram (src/hmm.cpp:108); the last phone of a word has three
+    # transitions at ln 1/3, the terminating silence two at ln 1/2 (src/hmm.cpp:110-122)
+    assert a["tr_off"][1] == n_words and np.array_equal(a["tr_logp"][:n_words], np.float32(5.0) * uni)
+    tied = a["ctx"][:, 1].copy()
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    emis, fo = _emissions_for(rng, a, words, 9, 6)
+    emis_d = ctx.array(emis)
+    for final_mode in (1, 0):
+        for beam in (1e10, 400.0, 60.0):
+            path, final, fstate, status = hmm.viterbi(emis_d, G, 1, fo, beam, final_mode)
+            n_ok = 0
+            for u in range(len(fo) - 1):
+                r = oracle.viterbi_graph(emis[fo[u]:fo[u + 1]], tied, a["tr_off"], a["tr_tgt"], a["tr_logp"], beam, 0, final_mode)
+                assert status[u] == r["status"], (final_mode, beam, u)
+                if r["status"] == 0:
+                    n_ok += 1
+                    assert final[u].tobytes() == r["final"].tobytes(), (final_mode, beam, u, final[u], r["final"])
+                    assert fstate[u] == r["final_state"]
+                    assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"]), (final_mode, beam, u)
+            if final_mode == 1 and beam >= 400.0:
+                assert n_ok == len(fo) - 1
+    # state-major emissions take the same path
+    p2, f2, s2, st2 = hmm.viterbi(ctx.array(np.ascontiguousarray(emis.T)), 1, len(emis), fo, 1e10, 1)
+    p1, f1, s1, st1 = hmm.viterbi(emis_d, G, 1, fo, 1e10, 1)
+    assert np.array_equal(p1, p2) and f1.tobytes() == f2.tobytes() and np.array_equal(st1, st2)
+    hmm.close()
+
+
+def test_graph_viterbi_equals_alignment_kernel_on_training_hmms(ctx, oracle):
+    """The general kernel on a training topology gives the alignment kernel's (and the training oracle's) score and path."""
+    rng = np.random.default_rng(7)
+    for _ in range(4):
+        ph = synth.phone_string(rng, 4)
+        ntr, tr, _ = host.build_training_hmm(ph)
+        S = len(ph)
+        off = np.zeros(S + 1, np.int32)
+        off[1:] = np.cumsum(ntr)
+        tgt = np.concatenate([np.arange(s, s + ntr[s]) for s in range(S)]).astype(np.int32)
+        lp = np.concatenate([tr[s, :ntr[s]] for s in range(S)]).astype(np.float32)
+        T = int(rng.integers(60, 200))
+        emis = (rng.standard_normal((T, G)) * 4 - 20).astype(np.float32)
+        fo = np.array([0, T], np.int64)
+        hmm = host.GraphHmm(ctx, off, tgt, lp, ph)
+        path, final, fstate, status = hmm.viterbi(ctx.array(emis), G, 1, fo, 1e10, 0)
+        r = oracle.viterbi(emis, ph, ntr, tr)
+        hb = host.HmmBatch(ctx, fo, [ntr], [tr], [ph.astype(np.int32)])
+        p_d, f_d, s_d = hb.viterbi(ctx.array(emis), G)
+        ctx.sync()
+        assert status[0] == 0 == r["status"] and fstate[0] == S - 1
+        assert final[0].tobytes() == r["final"].tobytes() == f_d.get()[0].tobytes()
+        assert np.array_equal(path, r["path"]) and np.array_equal(path, p_d.get())
+        hmm.close()
+
+
+def test_update_states_on_lexicon_transitions(ctx, oracle):
+    """hmm::update_states (src/hmm.cpp:361-366): pooled advance probabilities into the lexicon HMM's transitions, then
+    decoding with them (srx_decode_plan_set_transitions)."""
+    rng = np.random.default_rng(3)
+    words, uni = _lexicon(rng, 30)
+    a = host.build_lexicon_hmm(words, uni)
+    tied = a["ctx"][:, 1].copy()
+    C_ = 40
+    probsum = rng.uniform(5, 50, C_).astype(np.float32)
+    count = rng.integers(0, 100, C_).astype(np.int32)
+    count[5] = 0
+    new_tr = oracle.update_states(a["tr_off"], a["tr_logp"], tied, probsum, count)
+    assert not np.array_equal(new_tr, a["tr_logp"]) and np.array_equal(new_tr[:30], a["tr_logp"][:30])   # start state untouched
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    hmm.set_transitions(new_tr)
+    emis, fo = _emissions_for(rng, a, words, 8, 3)
+    path, final, fstate, status = hmm.viterbi(ctx.array(emis), G, 1, fo, 300.0, 1)
+    for u in range(len(fo) - 1):
+        r = oracle.viterbi_graph(emis[fo[u]:fo[u + 1]], tied, a["tr_off"], a["tr_tgt"], new_tr, 300.0, 0, 1)
+        assert status[u] == r["status"] == 0 and final[u].tobytes() == r["final"].tobytes()
+        assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"])
+    hmm.close()

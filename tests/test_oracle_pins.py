@@ -278,3 +278,29 @@ def test_oracle_matches_committed_vectors(oracle):
             a, b = z[k], fresh[k]
             assert a.shape == b.shape and a.dtype == b.dtype, k
             assert a.tobytes() == b.tobytes(), k
+
+
+def test_graph_viterbi_restatement_equals_training_viterbi_restatement(oracle):
+    """orc_viterbi_graph (arbitrary transition lists: the checker of the lexicon-HMM decode) reproduces orc_viterbi -- the
+    restatement that SURVEY.md section 4's accumulate-semantics fact pins -- bit for bit on training topologies, with and
+    without a beam and in both visiting orders."""
+    import numpy as np
+    from speechrecognition_amd import synth
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        ph = synth.phone_string(rng, int(rng.integers(1, 6)))
+        ntr, tr, _ = oracle.build_training_hmm(ph)
+        S = len(ph)
+        off = np.zeros(S + 1, np.int32)
+        off[1:] = np.cumsum(ntr)
+        tgt = np.concatenate([np.arange(s, s + ntr[s]) for s in range(S)]).astype(np.int32)
+        lp = np.concatenate([tr[s, :ntr[s]] for s in range(S)]).astype(np.float32)
+        T = int(rng.integers(3, 150))
+        emis = (rng.standard_normal((T, 40)) * 5 - 15).astype(np.float32)
+        for beam in (1e10, 40.0):
+            for order in (0, 1):
+                a = oracle.viterbi(emis, ph, ntr, tr, beam, order)
+                b = oracle.viterbi_graph(emis, ph, off, tgt, lp, beam, order, 0)
+                assert a["status"] == b["status"]
+                if a["status"] == 0:
+                    assert a["final"].tobytes() == b["final"].tobytes() and np.array_equal(a["path"], b["path"])
