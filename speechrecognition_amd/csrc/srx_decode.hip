@@ -23,6 +23,9 @@
 // the state count is bounded by memory, not by LDS; back-pointers are one int32 per (frame, state).  Every state is
 // visited every frame (activity is a flag, not a list): the sweep is dense, which a lexicon of a few thousand states
 // does not notice; a frontier list would be the next step for the full 125 k-word lexicon.
+// NaN emission scores (tied states whose parameters are NaN because training never visited them) are outside the
+// contract: the reference's result then depends on its map order; here a NaN candidate that arrives first is kept, as
+// in the reference, for ordinary targets, while the workgroup reduction of a fan-in target may pick differently.
 #include <algorithm>
 #include <vector>
 
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_viterbi_graph(int n_states, con
             return x;
         };
         // ---- B: every state as a target (src/hmm.cpp:171-183)
-        DecBest fb = {0.0f, -1};   // the frame's best accepted value
+        float fbv = -1e10f;        // next_best_logp: fmaxf over the accepted values, from -1e10f (src/hmm.cpp:161, 176, 181)
         for (int j = tid; j < n_states; j += DEC_THREADS) {
             const int q0 = in_off[j], q1 = in_off[j + 1];
             if (q1 - q0 >= FANIN_MIN) continue;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_viterbi_graph(int n_states, con
             if (b.idx >= 0) {
                 d_nxt[j] = b.v;
                 bp[(size_t)t * n_states + j] = b.idx;
-                if (fb.idx < 0 || b.v > fb.v) { fb.v = b.v; fb.idx = 0; }
+                fbv = fmaxf(fbv, b.v);
             }
         }
         for (int bi = 0; bi < n_big; bi++) {   // targets with many incoming edges: all threads, then one reduction
@@ -312,11 +315,15 @@ __global__ __launch_bounds__(DEC_THREADS) void k_viterbi_graph(int n_states, con
                     bp[(size_t)t * n_states + j] = b.idx;
                 }
             }
-            if (b.idx >= 0 && (fb.idx < 0 || b.v > fb.v)) { fb.v = b.v; fb.idx = 0; }
+            if (b.idx >= 0) fbv = fmaxf(fbv, b.v);
         }
-        // ---- C: current_best_logp = next_best_logp (src/hmm.cpp:161, 176, 181, 187)
-        fb = dec_block_reduce(fb, red);
-        cur_best = fb.idx >= 0 ? fmaxf(-1e10f, fb.v) : -1e10f;
+        // ---- C: current_best_logp = next_best_logp (src/hmm.cpp:187)
+        for (int o = 32; o > 0; o >>= 1) fbv = fmaxf(fbv, __shfl_xor(fbv, o, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6].v = fbv;
+        __syncthreads();
+        cur_best = red[0].v;
+        for (int w = 1; w < DEC_THREADS / 64; w++) cur_best = fmaxf(cur_best, red[w].v);
         float *tf = d_cur; d_cur = d_nxt; d_nxt = tf;
         unsigned char *ta = a_cur; a_cur = a_nxt; a_nxt = ta;
         __syncthreads();

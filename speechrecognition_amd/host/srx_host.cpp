@@ -769,6 +769,22 @@ logprob_t acoustic_model::operator()(featurevec &fv, phone::context ph) {
     return s[(size_t)tied_index(ph)];
 }
 
+// ============================================================================================ langmodel
+unigram_model::unigram_model(long count) : total_count(count), logtotal((float)std::log((double)count)) {}   // src/langmodel.cpp:12-15
+unigram_model::unigram_model(std::istream &in, long count) : total_count(count), logtotal((float)std::log((double)count)) {
+    string w;
+    long c;
+    while (in >> w >> c) put(w, c);   // (the reference's `while (in.good())` reads the last pair twice: same table)
+}
+void unigram_model::put(string w, long count) {
+    float logprob = (float)(std::log((double)count) - (double)logtotal);
+    probs[w] = logprob;
+}
+float unigram_model::get(string w) const {
+    std::map<string, float>::const_iterator it = probs.find(w);
+    return it != probs.end() ? it->second : -logtotal;   // an unseen word counts as seen once
+}
+
 // ============================================================================================ hmm
 hmm_state::hmm_state(phspec p) : ph(p), ctx(phone::context(p.first)), word(nullptr) {}
 float hmm_state::get_logprob(int i) const { return tr[i].second; }
@@ -809,7 +825,106 @@ hmm::hmm(vector<phone::phone> ph, acoustic_model *ac) : acm(ac), temp_acm(NULL),
     for (int i = 0; i < S; i++) idx_map[&states[i]] = i;
 }
 hmm::hmm(acoustic_model *ac, state_model *smo) : acm(ac), temp_acm(new acoustic_model(ac)), sm(smo) {}
-hmm::~hmm() {}
+
+// src/hmm.cpp:92-129: the topology comes from srx_hmm_build_lexicon (words in the map's order, first pronunciation each)
+hmm::hmm(pronlex &pr, unigram_model &uni, acoustic_model *ac, state_model *smo)
+    : acm(ac), temp_acm(new acoustic_model(ac)), sm(smo), general_topology(true) {
+    vector<int32_t> phone_off(1, 0), phones;
+    vector<float> logp;
+    vector<const string *> word_ptr;
+    for (std::map<string, pronlist>::iterator it = pr.pr.begin(); it != pr.pr.end(); it++) {
+        const vector<phone::phone> &p = it->second.pronunciations.at(0);
+        if (p.empty()) continue;   // (the reference would index states out of order for an empty pronunciation)
+        for (phone::phone q : p) phones.push_back((int32_t)q);
+        phone_off.push_back((int32_t)phones.size());
+        logp.push_back(uni.get(it->first));
+        word_ptr.push_back(&it->first);
+    }
+    const int W = (int)logp.size();
+    int64_t ns = 0, nt = 0;
+    int rc = srx_hmm_build_lexicon(W, phone_off.data(), phones.data(), logp.data(), (float)LMSF, nullptr, nullptr, nullptr, nullptr, nullptr, &ns, &nt);
+    if (rc != SRX_OK) throw srx_error(rc, srx_last_error(nullptr));
+    vector<int32_t> tr_off((size_t)ns + 1), tr_tgt((size_t)nt), ctx3((size_t)ns * 3), word_of((size_t)ns);
+    vector<float> tr_lp((size_t)nt);
+    rc = srx_hmm_build_lexicon(W, phone_off.data(), phones.data(), logp.data(), (float)LMSF, tr_off.data(), tr_tgt.data(), tr_lp.data(),
+                               ctx3.data(), word_of.data(), &ns, &nt);
+    if (rc != SRX_OK) throw srx_error(rc, srx_last_error(nullptr));
+    states.reserve((size_t)ns);
+    for (int64_t i = 0; i < ns; i++) {
+        hmm_state st(phspec((phone::phone)ctx3[(size_t)i * 3 + 1], i == 0 ? phone::BEGIN : phone::MIDDLE));
+        st.ctx = phone::context((phone::phone)ctx3[(size_t)i * 3], (phone::phone)ctx3[(size_t)i * 3 + 1], (phone::phone)ctx3[(size_t)i * 3 + 2]);
+        st.word = word_of[(size_t)i] >= 0 ? word_ptr[(size_t)word_of[(size_t)i]] : nullptr;
+        states.push_back(st);
+    }
+    for (int64_t i = 0; i < ns; i++)
+        for (int32_t t = tr_off[(size_t)i]; t < tr_off[(size_t)i + 1]; t++)
+            states[(size_t)i].tr.push_back(transition(&states[(size_t)tr_tgt[(size_t)t]], tr_lp[(size_t)t]));
+    for (int64_t i = 0; i < ns; i++) idx_map[&states[(size_t)i]] = (int)i;
+}
+hmm::~hmm() { srx_decode_plan_destroy(dplan); }
+
+path hmm::run_graph(vector<featurevec *> &fvs, float &prevp, float beam_width, int final_mode) {
+    path result;
+    const int64_t T = (int64_t)fvs.size();
+    if (T == 0 || states.empty()) {
+        if (srx::verbose()) std::cout << "NO PATH" << std::endl;
+        return result;
+    }
+    srx_ctx *ctx = srx::context();
+    if (!dplan) {
+        vector<int32_t> tr_off(1, 0), tr_tgt, tied;
+        vector<float> tr_lp;
+        for (hmm_state &st : states) {
+            for (transition &t : st.tr) {
+                tr_tgt.push_back(indexOf(t.first));
+                tr_lp.push_back(t.second);
+            }
+            tr_off.push_back((int32_t)tr_tgt.size());
+            tied.push_back(acm->tied_index(st.ctx));
+        }
+        check(srx_decode_plan_create(ctx, (int)states.size(), tr_off.data(), tr_tgt.data(), tr_lp.data(), tied.data(), &dplan));
+    }
+    vector<float> x;
+    pack_features(fvs, x);
+    Dev<float> d_x;
+    d_x.upload(x);
+    const int G = acm->num_states();
+    Dev<float> d_e((size_t)T * G), d_final(1);
+    check(srx_gmm_score_dev(ctx, acm->device(), g_mix_mode, g_score_path, d_x.p, 3 * NPARAMS, T, d_e.p, G, 1));
+    Dev<int32_t> d_path((size_t)T), d_status(1), d_fs(1);
+    const int64_t fo[2] = {0, T};
+    check(srx_viterbi_graph_dev(ctx, dplan, d_e.p, G, 1, fo, 1, beam_width, final_mode, d_path.p, d_final.p, d_fs.p, d_status.p));
+    int32_t status = 0;
+    d_status.download(&status, 1);
+    if (status != 0) {
+        if (srx::verbose()) std::cout << "NO PATH" << std::endl;
+        return result;
+    }
+    float fin = 0;
+    d_final.download(&fin, 1);
+    float nlp = fin / fvs.size();
+    if (srx::verbose()) std::cout << "Viterbi path has normalized logprob " << nlp << "\tdelta: " << nlp - prevp << std::endl;
+    prevp = nlp;
+    vector<int32_t> p = d_path.get();
+    for (int64_t t = 0; t < T; t++) result.push_back(&states[(size_t)p[(size_t)t]]);
+    return result;
+}
+
+path hmm::decode(vector<featurevec *> fvs, float &prevp, float beam_width) { return run_graph(fvs, prevp, beam_width, 1); }
+
+vector<string> hmm::transcript(const path &p) {
+    vector<string> words;
+    hmm_state *prev = nullptr;
+    for (hmm_state *s : p) {
+        if (s != prev && s->word) {
+            const int i = indexOf(s);
+            const bool first = i >= 1 && states[(size_t)i - 1].word != s->word;   // the state after the start state or after another word's silence
+            if (first) words.push_back(*s->word);
+        }
+        prev = s;
+    }
+    return words;
+}
 int hmm::indexOf(hmm_state *s) { return idx_map[s]; }
 
 namespace {
@@ -869,6 +984,7 @@ struct DeviceBatch {
 }  // namespace
 
 path hmm::viterbi(vector<featurevec *> fvs, float &prevp, float beam_width) {
+    if (general_topology) return run_graph(fvs, prevp, beam_width, 0);
     path result;
     const int64_t T = (int64_t)fvs.size();
     if (T == 0 || states.empty()) {
@@ -1049,7 +1165,13 @@ void hmm::train(vector<utterance> &ut, int iterations) {
 void hmm::update_states() {
     for (size_t i = 1; i < states.size(); i++) {
         float p = (*sm)(&states[i]);
-        if (states[i].tr.size() >= 2) states[i].set_adv_prob(p);
+        if (states[i].tr.size() >= 2) states[i].set_adv_prob(p);   // (every lexicon state has two or three; a one-transition state would be UB in the reference)
+    }
+    if (dplan) {   // the device image follows
+        vector<float> tr_lp;
+        for (hmm_state &st : states)
+            for (transition &t : st.tr) tr_lp.push_back(t.second);
+        check(srx_decode_plan_set_transitions(dplan, tr_lp.data()));
     }
 }
 

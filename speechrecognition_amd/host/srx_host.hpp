@@ -47,6 +47,7 @@
 #define MAX_ADV_PROB 0.55f           // src/hmm.hpp:29
 #define HMM_BLEND_FAC 0.2f           // src/hmm.hpp:30
 #define GMM_BLEND_FAC 0.2f           // src/hmm.hpp:31
+#define LMSF 5                       // src/hmm.hpp:33: language model scaling factor
 #ifndef EM_ITERS
 #define EM_ITERS 80                  // src/hmm.cpp:247
 #endif
@@ -228,6 +229,19 @@ public:
     std::vector<phone::phone> pronounce(std::string s);        // src/pronounce.cpp:260-278
 };
 
+// ------------------------------------------------------------------------------------------ langmodel.hpp (subset)
+// Unigram log-probabilities: what the lexicon HMM's start transitions are built from (src/hmm.cpp:108).
+class unigram_model {                                                                    // src/langmodel.hpp:34-52
+public:
+    std::map<std::string, float> probs;
+    long total_count;
+    float logtotal;
+    unigram_model(long total_count);                          // an empty table: every word gets -logtotal
+    unigram_model(std::istream &in, long total_count);        // one "word count" pair per line
+    void put(std::string w, long count);                      // src/langmodel.cpp:16-19
+    float get(std::string w) const;                           // src/langmodel.cpp:22-28
+};
+
 // ------------------------------------------------------------------------------------------ gmm.hpp
 typedef long double prob_t;
 typedef float logprob_t;
@@ -321,16 +335,30 @@ public:
     acoustic_model *acm, *temp_acm;
     state_model *sm;
     hmm(std::vector<phone::phone> ph, acoustic_model *ac);         // training HMM, src/hmm.cpp:56-88
-    // The trainer object: stands where the reference's lexicon HMM stands in main (src/main.cpp:58-60) and
-    // carries acm / temp_acm / sm; the lexicon topology itself is out of scope.
+    // The lexicon HMM, src/hmm.cpp:92-129: start state, per word (first pronunciation) its phone states and a terminating
+    // silence, start transitions LMSF * unigram log-probability.  As in src/main.cpp:58 it is also the trainer object.
+    hmm(pronlex &pr, unigram_model &uni, acoustic_model *ac, state_model *smo);
+    // A trainer object without the lexicon topology (carries acm / temp_acm / sm only): for callers that train and never decode.
     hmm(acoustic_model *ac, state_model *smo);
     ~hmm();
     int indexOf(hmm_state *);
-    path viterbi(std::vector<featurevec *> fvs, float &prevp, float beam_width = 1e10);   // src/hmm.cpp:150-224
+    // src/hmm.cpp:150-224.  On a training HMM: batched alignment kernel.  On the lexicon HMM: the general-topology kernel
+    // with the end condition the reference is compiled with (the path must end in the LAST state, src/hmm.cpp:210).
+    path viterbi(std::vector<featurevec *> fvs, float &prevp, float beam_width = 1e10);
+    // The recognition variant the reference has commented out (src/hmm.cpp:196-209): the path ends in the best active
+    // state.  Empty path when every path was pruned (the reference would `throw 1729`).
+    path decode(std::vector<featurevec *> fvs, float &prevp, float beam_width = 1e10);
+    // The words a path of the lexicon HMM passes through (a word counts when the path enters its first state).
+    std::vector<std::string> transcript(const path &p);
     void train_transition_probabilities(path p);                                          // src/hmm.cpp:229-243
     void train(std::vector<utterance> &ut);                                               // src/hmm.cpp:250-358
     void train(std::vector<utterance> &ut, int iterations);    // same with EM_ITERS as a run-time value
     void update_states();                                                                 // src/hmm.cpp:361-366
+
+private:
+    bool general_topology = false;       // lexicon HMM: transitions are an arbitrary list
+    srx_decode_plan *dplan = nullptr;    // its device image, built on first use, refreshed by update_states
+    path run_graph(std::vector<featurevec *> &fvs, float &prevp, float beam_width, int final_mode);
 };
 
 // ------------------------------------------------------------------------------------------ utterance.hpp

@@ -5,6 +5,10 @@
 //   srx --mode mfcc  --voxforge DIR/ [--list _list]  [--window 320 --shift 160] [--batch 256] [--verbose]
 //   srx --mode train --voxforge DIR/ [--list _train] [--iters 80] [--mix 1] [--seed 1] [--out model.txt]
 //   srx --mode align --voxforge DIR/ [--list _train] [--model model.txt] [--out paths.txt]
+//   srx --mode decode --voxforge DIR/ --lexicon cmu.txt --model model.txt [--unigram FILE --unigram-total N] [--beam 200] [--states]
+//        free decoding over the lexicon HMM (src/hmm.cpp:92-129) with the recognition end condition the reference has
+//        commented out (src/hmm.cpp:196-209): one line per utterance, "<index> <normalised logprob> WORD WORD ..."
+//        (--states: the state indices of the path instead of the words)
 //   RANK=r WORLD_SIZE=n LOCAL_RANK=g SRX_COMM_FILE=/shared/path srx --mode train ...    one process per GPU: every rank
 //        loads its share of the utterances, statistics are all-reduced with RCCL, rank 0 writes --out
 //   srx --mode pronounce --lexicon cmu.txt [--prefixes prefixes.txt --suffixes suffixes.txt]   (text lines on stdin)
@@ -198,7 +202,7 @@ int main(int argc, char **argv) {
     srx::set_verbose(flag(argc, argv, "--verbose"));
     const string lexicon = arg(argc, argv, "--lexicon", "");
     if (mode.empty() || (dir.empty() && mode != "pronounce") || (mode == "pronounce" && lexicon.empty())) {
-        cerr << "usage: srx --mode mfcc|train|align --voxforge DIR/ [options] | --mode pronounce --lexicon FILE"
+        cerr << "usage: srx --mode mfcc|train|align|decode --voxforge DIR/ [options] | --mode pronounce --lexicon FILE"
                 "  (see the head of srx_main.cpp)" << endl;
         return 2;
     }
@@ -224,7 +228,7 @@ int main(int argc, char **argv) {
         if (mode == "mfcc")
             return run_mfcc(dir, arg(argc, argv, "--list", "_list"), (unsigned)atoi(arg(argc, argv, "--window", "320").c_str()),
                             (unsigned)atoi(arg(argc, argv, "--shift", "160").c_str()), atoi(arg(argc, argv, "--batch", "256").c_str()));
-        if (mode == "train" || mode == "align") {
+        if (mode == "train" || mode == "align" || mode == "decode") {
             srx::init_distributed();   // RANK / WORLD_SIZE / LOCAL_RANK of a launcher; a plain run is world 1
             srx::seed_random((unsigned)atoi(arg(argc, argv, "--seed", "1").c_str()));
             phone::ties acm_ties(phone::ties::NULL_CONTEXT);   // src/main.cpp:34-36
@@ -250,6 +254,34 @@ int main(int argc, char **argv) {
                 const string out = arg(argc, argv, "--out", "");
                 if (!out.empty() && (srx::rank() == 0 || flag(argc, argv, "--dump-every-rank"))) dump_model(*h.acm, out);   // every rank holds the same model
                 cout << "trained " << h.acm->num_states() << " tied states on " << ut.size() << " utterances" << endl;
+            } else if (mode == "decode") {
+                if (!pron) {
+                    cerr << "--mode decode needs --lexicon" << endl;
+                    return 2;
+                }
+                // src/main.cpp:29-31, 58: the unigram table (absent: every word counts as seen once) and the lexicon HMM
+                const long total = atol(arg(argc, argv, "--unigram-total", "111452435771").c_str());
+                const string uni_file = arg(argc, argv, "--unigram", "");
+                ifstream lm(uni_file.c_str());
+                unigram_model uni = uni_file.empty() ? unigram_model(total) : unigram_model(lm, total);
+                hmm h(pron->main, uni, &acm, new state_model(&hmm_ties));
+                const float beam = (float)atof(arg(argc, argv, "--beam", "1e10").c_str());
+                const bool want_states = flag(argc, argv, "--states");
+                const string out = arg(argc, argv, "--out", "");
+                FILE *f = out.empty() ? stdout : fopen(out.c_str(), "w");
+                if (!f) throw 1;
+                fprintf(f, "lexicon-hmm %zu states\n", h.states.size());
+                for (size_t u = 0; u < ut.size(); u++) {
+                    float prevp = 0;
+                    path p = h.decode(ut[u].features, prevp, beam);
+                    fprintf(f, "%zu %.9g", u, p.empty() ? 0.0 : (double)prevp);
+                    if (want_states)
+                        for (hmm_state *s : p) fprintf(f, " %d", h.indexOf(s));
+                    else
+                        for (const string &w : h.transcript(p)) fprintf(f, " %s", w.c_str());
+                    fprintf(f, "\n");
+                }
+                if (f != stdout) fclose(f);
             } else {
                 const string out = arg(argc, argv, "--out", "");
                 FILE *f = out.empty() ? stdout : fopen(out.c_str(), "w");

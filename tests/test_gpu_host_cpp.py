@@ -279,7 +279,7 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
         assert abs(float(row[1]) - r["prevp"]) <= 1e-6 * abs(r["prevp"])
 
 
-def test_headless_driver_prompts_through_the_lexicon(tmp_path):
+def test_headless_driver_prompts_through_the_lexicon(oracle, tmp_path):
     """--lexicon: transcripts from etc/PROMPTS pronounced by the host layer's pronouncer (src/main.cpp:27, 43;
     src/utterance.cpp:14-28) give the alignment that the same phone strings give through etc/PHONES; an
     unpronounceable line drops its utterance (src/main.cpp:44-48)."""
@@ -323,6 +323,72 @@ def test_headless_driver_prompts_through_the_lexicon(tmp_path):
     m1, m2 = nums(root + "m.txt"), nums(root + "m2.txt")
     assert m1.size == 40 * 26 and np.isfinite(m1).sum() >= 26 * 10
     np.testing.assert_allclose(m2, m1, rtol=1e-9, equal_nan=True)   # summation order inside the device sums is not fixed
+
+    # ---- DECODE mode: the lexicon HMM of src/hmm.cpp:92-129 built by the C++ constructor from the same lexicon file, free
+    # decoding with the recognition end condition (src/hmm.cpp:196-209).  Checked against the oracle's lexicon constructor
+    # and general-topology Viterbi on the emissions the same exact-path scoring kernel gives (parity unpinned, see
+    # tests/test_gpu_decode.py).  The trained model holds NaN rows for phones the corpus never visits (reference behaviour);
+    # decoding is run under a model whose every row is finite: the trained rows, and the corpus mean / variance elsewhere.
+    from speechrecognition_amd import SRX_MIX_COMPONENT0, SRX_SCORE_EXACT, host
+    txt = open(root + "m.txt").read().split("\n")
+    gm = np.array([[float(v) for v in ln.split()[1:]] for ln in txt if ln.startswith("mean")]).reshape(40, 1, 13)
+    gv = np.array([[float(v) for v in ln.split()[1:]] for ln in txt if ln.startswith("var")]).reshape(40, 1, 13)
+    gw = np.array([float(ln.split()[1]) for ln in txt if ln.startswith("w ")], np.float32).reshape(40, 1)
+    bad = np.isnan(gm).any(axis=(1, 2)) | np.isnan(gv).any(axis=(1, 2)) | np.isnan(gw[:, 0])
+    assert bad.any() and (~bad).sum() >= 10
+    gm[bad], gv[bad], gw[bad] = np.nanmean(gm[~bad], axis=0), np.nanmean(gv[~bad], axis=0) * 4.0, 1.0
+    with open(root + "mfin.txt", "w") as f:
+        f.write("srx-model 40 1 13\n")
+        for g_ in range(40):
+            f.write("state 0 %d 0\nw %r\nmean %s\nvar %s\n" % (g_, float(gw[g_, 0]), " ".join(repr(float(v)) for v in gm[g_, 0]),
+                                                               " ".join(repr(float(v)) for v in gv[g_, 0])))
+    out = _run([SRX, "--mode", "decode", "--voxforge", root, "--model", root + "mfin.txt", "--lexicon", lex[0], "--prefixes", lex[1],
+                "--suffixes", lex[2], "--beam", "250", "--states", "--unigram-total", "1000"], env)
+    rows = [ln.split() for ln in out.splitlines() if ln and ln[0].isdigit()]
+    outw = _run([SRX, "--mode", "decode", "--voxforge", root, "--model", root + "mfin.txt", "--lexicon", lex[0], "--prefixes", lex[1],
+                 "--suffixes", lex[2], "--beam", "250", "--unigram-total", "1000"], env)
+    rows_w = [ln.split() for ln in outw.splitlines() if ln and ln[0].isdigit()]
+    # the lexicon as the reference's map holds it: spelling -> first pronunciation, sorted by spelling
+    # (through the oracle's lexicon parser, which restates the reference's quirks: alternates "(1)" fold into the word and
+    #  only the first listed pronunciation is used, src/hmm.cpp:96; a line ending in blanks repeats its last phone)
+    entries = {w: np.array(p[0], np.int32) for w, p in pr.main.items() if len(p[0]) > 0}
+    spell = sorted(entries)
+    uni = np.full(len(spell), -np.float32(np.log(1000.0)), np.float32)        # an empty unigram table: -logtotal for every word
+    L = oracle.build_lexicon_hmm([entries[w] for w in spell], uni)
+    assert ("lexicon-hmm %d states" % L["n_states"]) in out
+    tied = L["ctx"][:, 1].copy()                       # NULL_CONTEXT ties: the tied state of a context is its phone
+    c2 = host.Context(0)
+    model = host.AcousticModel(c2, 40, 1, 13)
+    model.set(gm, gv, gw)
+    used = [(f2, name) for fo_ in folders for (f2, name) in sorted(samples) if f2 == fo_]
+    assert len(rows) == 5 == len(rows_w)
+    n_words_seen = 0
+    ui = 0
+    for (f2, name), text in zip(used, texts):
+        try:
+            pr.pronounce(text)
+        except P.Unpronounceable:
+            continue                                   # the driver skipped this utterance ("Caught exception 1")
+        feats = oracle.read_features(_read_mfc(os.path.join(root, f2, "mfc", name)), 2)
+        e = model.score(feats, SRX_MIX_COMPONENT0, SRX_SCORE_EXACT)
+        r = oracle.viterbi_graph(e, tied, L["tr_off"], L["tr_tgt"], L["tr_logp"], 250.0, 0, 1)
+        row = rows[ui]
+        if r["status"] != 0:
+            assert len(row) == 2
+        else:
+            assert [int(v) for v in row[2:]] == list(r["path"]), ui
+            assert abs(float(row[1]) - float(r["final"]) / len(feats)) <= 1e-6 * abs(float(r["final"]) / len(feats))
+            # the word line: a word is counted when the path enters its first state
+            first = np.flatnonzero((L["word_of"] >= 0) & (np.roll(L["word_of"], 1) != L["word_of"]))
+            p_ = r["path"]
+            enter = [p_[0]] + [b_ for a_, b_ in zip(p_[:-1], p_[1:]) if a_ != b_]
+            want = [spell[L["word_of"][s_]] for s_ in enter if s_ in first]
+            assert rows_w[ui][2:] == want, ui
+            n_words_seen += len(want)
+        ui += 1
+    assert ui == 5 and n_words_seen >= 5
+    model.close()
+    c2.close()
 
 
 def test_comm_rccl_single_rank_and_noop(ctx):
