@@ -93,6 +93,54 @@ int main(int argc, char **argv) {
         featurevec var = variance(uts, mu);
         dump("corpus_mean", mu.coeffs, FV_LEN);
         dump("corpus_var", var.coeffs, FV_LEN);
+        // ---- state_model + lexicon HMM + update_states (src/hmm.cpp:39-51, 92-129, 361-366; src/main.cpp:58) ----
+        phone::ties hmm_ties(phone::ties::PHONE_CLASSES);
+        state_model smod(&hmm_ties);
+        printf("aug");   // every path frame whose state has an advance transition: tied class triple + get_adv_prob()
+        for (hmm_state *s : p)
+            if (s->tr.size() >= 2) {
+                smod.augment(s);
+                phone::context c = hmm_ties(s->ctx);
+                printf(" %d %d %d %.9g", (int)c.prev, (int)c.curr, (int)c.next, (double)s->get_adv_prob());
+            }
+        printf("\n");
+        pronlex lx;
+        lx.add("HELLO", {HH, AH, L, OW});
+        lx.add("WORLD", {W, ER, L, D});
+        lx.add("A", {AH});
+        lx.add("LOW", {L, OW});
+        unigram_model uni(1000);
+        uni.put("HELLO", 50);
+        uni.put("WORLD", 20);
+        printf("uni %.9g %.9g %.9g\n", (double)uni.get("HELLO"), (double)uni.get("WORLD"), (double)uni.get("A"));
+        hmm lex(lx, uni, &acm, &smod);
+        printf("lex_nstates %zu\n", lex.states.size());
+        printf("lex_ctx");
+        for (hmm_state &s : lex.states) {
+            phone::context c = hmm_ties(s.ctx);
+            printf(" %d %d %d", (int)c.prev, (int)c.curr, (int)c.next);
+        }
+        printf("\nlex_ntr");
+        for (hmm_state &s : lex.states) printf(" %zu", s.tr.size());
+        printf("\nlex_tr_before");
+        for (hmm_state &s : lex.states)
+            for (transition &t : s.tr) printf(" %.9g", (double)t.second);
+        printf("\n");
+        float lp2 = 0;
+        path dp = lex.decode(fvs, lp2, 300.0f);      // builds the device image before update_states refreshes it
+        lex.update_states();
+        printf("lex_tr_after");
+        for (hmm_state &s : lex.states)
+            for (transition &t : s.tr) printf(" %.9g", (double)t.second);
+        printf("\n");
+        float lp3 = 0;
+        path dp2 = lex.decode(fvs, lp3, 300.0f);
+        printf("lex_decode_prevp %.9g %.9g\n", (double)lp2, (double)lp3);
+        printf("lex_path_after");
+        for (hmm_state *s : dp2) printf(" %d", lex.indexOf(s));
+        printf("\nlex_words_after");
+        for (const string &w : lex.transcript(dp2)) printf(" %s", w.c_str());
+        printf("\n");
         vector<featurevec *> few(fvs.begin(), fvs.begin() + 4);
         path none = h.viterbi(few, prevp, 1e10);   // 4 frames cannot reach state 10
         printf("no_path_len %zu\n", none.size());

@@ -117,6 +117,33 @@ def test_host_api_calls_match_oracle(oracle, tmp_path):
     want = np.concatenate([tr2[s, :ntr[s]] for s in range(11)])
     np.testing.assert_allclose(f("tr"), want, rtol=3e-6, atol=1e-7)
     assert d["no_path_len"] == ["0"]
+    # ---- state_model::augment / operator() and hmm::update_states on the lexicon HMM (a24; src/hmm.cpp:39-51, 361-366) ----
+    aug = np.array([float(v) for v in d["aug"]]).reshape(-1, 4)
+    adv_path = np.exp(tr2[r["path"], 1].astype(np.float32)).astype(np.float32)[ntr[r["path"]] >= 2]
+    np.testing.assert_allclose(aug[:, 3], adv_path, rtol=2e-6)      # get_adv_prob() of the re-estimated path states, in path order
+    keys = [tuple(int(v) for v in row[:3]) for row in aug]
+    classes = {k: i for i, k in enumerate(dict.fromkeys(keys))}
+    ps, cnt = oracle.state_model(np.array([classes[k] for k in keys], np.int32), aug[:, 3].astype(np.float32), len(classes) + 1)
+    np.testing.assert_allclose(f("uni"), [np.float32(np.log(50.0) - np.float32(np.log(1000.0))), np.float32(np.log(20.0) - np.float32(np.log(1000.0))),
+                                          -np.float32(np.log(1000.0))], rtol=1e-6)       # src/langmodel.cpp:16-28
+    # the lexicon the C++ constructor was given, through the oracle's constructor (words in map order: A, HELLO, LOW, WORLD)
+    words = [np.array(w, np.int32) for w in ([3], [16, 3, 21, 25], [21, 25], [36, 12, 21, 9])]
+    uni_lp = np.array([f("uni")[2], f("uni")[0], f("uni")[2], f("uni")[1]], np.float32)
+    L = oracle.build_lexicon_hmm(words, uni_lp)
+    assert int(d["lex_nstates"][0]) == L["n_states"] == 1 + 2 + 5 + 3 + 5
+    assert [int(v) for v in d["lex_ntr"]] == list(np.diff(L["tr_off"]))
+    np.testing.assert_allclose(f("lex_tr_before"), L["tr_logp"], rtol=1e-6)
+    lex_keys = [tuple(int(v) for v in f("lex_ctx")[3 * i:3 * i + 3]) for i in range(L["n_states"])]
+    cls = np.array([classes.get(k, len(classes)) for k in lex_keys], np.int32)      # a class never augmented: count 0 -> 0.5
+    assert (cls < len(classes)).any() and (cls == len(classes)).any()
+    want_tr = oracle.update_states(L["tr_off"], L["tr_logp"], cls, ps, cnt)
+    np.testing.assert_allclose(f("lex_tr_after"), want_tr, rtol=3e-6, atol=1e-7)
+    assert np.array_equal(want_tr[:4], L["tr_logp"][:4]) and not np.allclose(want_tr, L["tr_logp"])   # the start state keeps its LM scores
+    # decoding with the refreshed transitions (device image follows update_states): the oracle on the same exact-path emissions
+    rl = oracle.viterbi_graph(emis, L["ctx"][:, 1].copy(), L["tr_off"], L["tr_tgt"], f("lex_tr_after").astype(np.float32), 300.0, 0, 1)
+    assert rl["status"] == 0 and [int(v) for v in d["lex_path_after"]] == list(rl["path"])
+    assert abs(f("lex_decode_prevp")[1] - float(rl["final"]) / len(feats)) <= 1e-6 * abs(float(rl["final"]) / len(feats))
+    assert f("lex_decode_prevp")[0] != f("lex_decode_prevp")[1]
     mu, var = oracle.corpus_mean_var(feats, 13)   # reference: f32 running sums; device: f64 sums
     np.testing.assert_allclose(f("corpus_mean"), mu, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(f("corpus_var"), var, rtol=1e-4)
@@ -279,7 +306,7 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
         assert abs(float(row[1]) - r["prevp"]) <= 1e-6 * abs(r["prevp"])
 
 
-def test_headless_driver_prompts_through_the_lexicon(oracle, tmp_path):
+def test_headless_driver_prompts_through_the_lexicon(ctx, oracle, tmp_path):
     """--lexicon: transcripts from etc/PROMPTS pronounced by the host layer's pronouncer (src/main.cpp:27, 43;
     src/utterance.cpp:14-28) give the alignment that the same phone strings give through etc/PHONES; an
     unpronounceable line drops its utterance (src/main.cpp:44-48)."""
@@ -357,8 +384,7 @@ def test_headless_driver_prompts_through_the_lexicon(oracle, tmp_path):
     L = oracle.build_lexicon_hmm([entries[w] for w in spell], uni)
     assert ("lexicon-hmm %d states" % L["n_states"]) in out
     tied = L["ctx"][:, 1].copy()                       # NULL_CONTEXT ties: the tied state of a context is its phone
-    c2 = host.Context(0)
-    model = host.AcousticModel(c2, 40, 1, 13)
+    model = host.AcousticModel(ctx, 40, 1, 13)
     model.set(gm, gv, gw)
     used = [(f2, name) for fo_ in folders for (f2, name) in sorted(samples) if f2 == fo_]
     assert len(rows) == 5 == len(rows_w)
@@ -388,7 +414,6 @@ def test_headless_driver_prompts_through_the_lexicon(oracle, tmp_path):
         ui += 1
     assert ui == 5 and n_words_seen >= 5
     model.close()
-    c2.close()
 
 
 def test_comm_rccl_single_rank_and_noop(ctx):
