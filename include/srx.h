@@ -129,6 +129,16 @@ int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *sam
 int srx_mfcc_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples, const int64_t *sample_off,
                    int n_utt, float *ceps, int64_t *frame_off);
 
+/* Clip::partial_dft  src/clip.cpp:174-194 of every frame of the batch, stand-alone: spec[frame][bin_max] (bin_max =
+ * srx_mfcc_plan_bin_max) = the magnitudes sqrt(re^2 + im^2) / sqrt(window) over the first half window, including the
+ * mirror branch for bins beyond N/2 (src/clip.cpp:177, 186-192).  The plan's normalisation / pre-emphasis settings apply
+ * as in srx_mfcc_batch*.  (Inside srx_mfcc_batch these values never leave the chip.) */
+int srx_partial_dft_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev, const int64_t *sample_off_dev,
+                              int n_utt, const int64_t *frame_off_dev, int64_t total_frames, float *scratch_scale_dev,
+                              float *spec_dev);
+int srx_partial_dft_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples, const int64_t *sample_off, int n_utt,
+                          float *spec, int64_t *frame_off);
+
 /* Clip::rmsAmplitude + Clip::normalizeVolume  src/clip.cpp:151-164 (in place, per utterance) */
 int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt,
                              float target_rms, float *scratch_scale_dev);

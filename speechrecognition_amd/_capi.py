@@ -68,6 +68,8 @@ SIGNATURES = {
     "srx_mfcc_frame_offsets": (C.c_int, [C.POINTER(srx_mfcc_cfg), vp, C.c_int, vp]),
     "srx_mfcc_batch_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]),
     "srx_mfcc_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp]),
+    "srx_partial_dft_batch_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]),
+    "srx_partial_dft_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp]),
     "srx_normalize_volume_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_float, vp]),
     "srx_scale_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "srx_rms_amplitude_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),

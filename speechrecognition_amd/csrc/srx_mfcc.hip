@@ -112,7 +112,9 @@ struct MfccArgs {
     const int64_t *foff;
     const float *scale;  // may be null
     const float *win, *twid, *fbm, *dctm;
-    float *ceps;
+    float *ceps;   // may be null (spectrum only)
+    float *spec;   // may be null; [total_frames][bin_max]: the output of Clip::partial_dft for every frame
+    int bin_max;
     int64_t total_frames;
     int n_utt, hop, half, KH, NB, NFP, n_ceps, nfilt;
     int preemph;
@@ -232,6 +234,14 @@ __global__ __launch_bounds__(256) void k_mfcc_tile(MfccArgs a) {
                 for (int r = 0; r < 4; r++)
                     MAG[(16 * w + kq * 4 + r) * a.ldM + g * GB + t * 16 + (lane & 15)] = mag[g][t][r];
     __syncthreads();
+    if (a.spec) {   // Clip::partial_dft's out[0 .. bin_max) of every frame of the tile (src/clip.cpp:174-194)
+        for (int idx = tid; idx < TILE_F * a.bin_max; idx += 256) {
+            const int row = idx / a.bin_max, b = idx - row * a.bin_max;
+            const int64_t f = F0 + row;
+            if (f < a.total_frames) a.spec[f * a.bin_max + b] = MAG[row * a.ldM + b];
+        }
+        if (!a.ceps) return;   // (uniform: no barrier is skipped by part of the workgroup)
+    }
 
     // ---- GEMM2: filterbank  [16 rows][NB] x [NB][NFP], NFP <= 64 (4 tiles) ----
     const int nft = a.NFP / 16;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(256) void k_mfcc_tile(MfccArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int64_t f = F0 + 16 * w + kq * 4 + r;
-            if (f < a.total_frames) a.ceps[f * a.n_ceps + j] = cacc[r];
+            if (f < a.total_frames) a.ceps[f * a.n_ceps + j] = cacc[r];   // (a.ceps is non-null here: the spectrum-only call returned)
         }
     }
 }
@@ -382,11 +392,9 @@ static int round_ld(int n) {  // smallest 2*odd >= n
     return v;
 }
 
-extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev,
-                                  const int64_t *sample_off_dev, int n_utt, const int64_t *frame_off_dev,
-                                  int64_t total_frames, float *scratch_scale_dev, float *ceps_dev) {
-    SRX_ENTER(ctx, "srx_mfcc_batch_dev");
-    SRX_REQUIRE(ctx, plan && samples_dev && sample_off_dev && frame_off_dev && ceps_dev, "srx_mfcc_batch_dev: null argument");
+static int mfcc_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev, const int64_t *sample_off_dev, int n_utt,
+                       const int64_t *frame_off_dev, int64_t total_frames, float *scratch_scale_dev, float *ceps_dev, float *spec_dev) {
+    SRX_REQUIRE(ctx, plan && samples_dev && sample_off_dev && frame_off_dev && (ceps_dev || spec_dev), "srx_mfcc_batch_dev: null argument");
     SRX_REQUIRE(ctx, n_utt >= 0 && total_frames >= 0, "srx_mfcc_batch_dev: negative size");
     if (n_utt == 0 || total_frames == 0) return SRX_OK;
     const srx_mfcc_cfg &c = plan->cfg;
@@ -399,14 +407,14 @@ extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const
         }
         SRX_LAUNCH_CHECK(ctx);
     }
-    if (plan->ks16 > 0 && plan->path != SRX_MFCC_F32)
+    if (!spec_dev && plan->ks16 > 0 && plan->path != SRX_MFCC_F32)
         return srx_mfcc16_launch(ctx, plan, samples_dev, sample_off_dev, n_utt, frame_off_dev, total_frames,
                                  c.normalize ? scratch_scale_dev : nullptr, ceps_dev);
     MfccArgs a;
     a.x = samples_dev; a.soff = sample_off_dev; a.foff = frame_off_dev;
     a.scale = c.normalize ? scratch_scale_dev : nullptr;
     a.win = plan->win; a.twid = plan->twid; a.fbm = plan->fbm; a.dctm = plan->dctm;
-    a.ceps = ceps_dev; a.total_frames = total_frames; a.n_utt = n_utt; a.hop = c.frame_shift;
+    a.ceps = ceps_dev; a.spec = spec_dev; a.bin_max = plan->bin_max; a.total_frames = total_frames; a.n_utt = n_utt; a.hop = c.frame_shift;
     a.half = plan->half; a.KH = plan->KH; a.NB = plan->NB; a.NFP = plan->NFP; a.n_ceps = c.n_ceps; a.nfilt = plan->nfilt;
     a.preemph = c.preemphasis; a.alpha = c.alpha; a.rootn_inv = plan->rootn_inv;
     a.ldA = round_ld(plan->KH);
@@ -426,6 +434,49 @@ extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const
         hipLaunchKernelGGL(k_mfcc_tile, dim3((unsigned)nblk), dim3(256), lds_bytes, ctx->stream, a);
     }
     SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+extern "C" int srx_mfcc_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev,
+                                  const int64_t *sample_off_dev, int n_utt, const int64_t *frame_off_dev,
+                                  int64_t total_frames, float *scratch_scale_dev, float *ceps_dev) {
+    SRX_ENTER(ctx, "srx_mfcc_batch_dev");
+    SRX_REQUIRE(ctx, ceps_dev, "srx_mfcc_batch_dev: null argument");
+    return mfcc_launch(ctx, plan, samples_dev, sample_off_dev, n_utt, frame_off_dev, total_frames, scratch_scale_dev, ceps_dev, nullptr);
+}
+
+// Clip::partial_dft (src/clip.cpp:174-194) of every frame, stand-alone: the magnitudes the fused kernel keeps in LDS,
+// written out (f32 matrix-core path; the plan's normalisation / pre-emphasis settings apply as in srx_mfcc_batch_dev).
+extern "C" int srx_partial_dft_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev,
+                                         const int64_t *sample_off_dev, int n_utt, const int64_t *frame_off_dev,
+                                         int64_t total_frames, float *scratch_scale_dev, float *spec_dev) {
+    SRX_ENTER(ctx, "srx_partial_dft_batch_dev");
+    SRX_REQUIRE(ctx, spec_dev, "srx_partial_dft_batch_dev: null argument");
+    return mfcc_launch(ctx, plan, samples_dev, sample_off_dev, n_utt, frame_off_dev, total_frames, scratch_scale_dev, nullptr, spec_dev);
+}
+
+extern "C" int srx_partial_dft_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples, const int64_t *sample_off, int n_utt,
+                                     float *spec, int64_t *frame_off) {
+    SRX_ENTER(ctx, "srx_partial_dft_batch");
+    SRX_REQUIRE(ctx, plan && samples && sample_off && spec && frame_off && n_utt >= 0, "srx_partial_dft_batch: bad argument");
+    int rc = srx_mfcc_frame_offsets(&plan->cfg, sample_off, n_utt, frame_off);
+    if (rc != SRX_OK) return srx_fail(ctx, rc, "%s", srx_last_error(nullptr));
+    if (n_utt == 0) return SRX_OK;
+    SRX_REQUIRE(ctx, sample_off[0] == 0, "srx_partial_dft_batch: sample_off[0] must be 0");
+    const int64_t ns = sample_off[n_utt], nf = frame_off[n_utt];
+    DevBuf dx, dso, dfo, dsc, ds;
+    SRX_HIP(ctx, dx.alloc(ns * sizeof(float)));
+    SRX_HIP(ctx, dso.alloc((n_utt + 1) * sizeof(int64_t)));
+    SRX_HIP(ctx, dfo.alloc((n_utt + 1) * sizeof(int64_t)));
+    SRX_HIP(ctx, dsc.alloc(n_utt * sizeof(float)));
+    SRX_HIP(ctx, ds.alloc(nf * plan->bin_max * sizeof(float)));
+    SRX_HIP(ctx, hipMemcpyAsync(dx.p, samples, ns * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    SRX_HIP(ctx, hipMemcpyAsync(dso.p, sample_off, (n_utt + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    SRX_HIP(ctx, hipMemcpyAsync(dfo.p, frame_off, (n_utt + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = srx_partial_dft_batch_dev(ctx, plan, dx.as<float>(), dso.as<int64_t>(), n_utt, dfo.as<int64_t>(), nf, dsc.as<float>(), ds.as<float>());
+    if (rc != SRX_OK) return rc;
+    SRX_HIP(ctx, hipMemcpyAsync(spec, ds.p, nf * plan->bin_max * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SRX_OK;
 }
 

@@ -181,6 +181,18 @@ class MfccPlan:
         assert (fo == fo2).all()
         return ceps, fo
 
+    def partial_dft(self, samples, sample_off):
+        """Clip::partial_dft (src/clip.cpp:174-194) of every frame -> (spec [total_frames, bin_max], frame_off)."""
+        samples = np.ascontiguousarray(samples, dtype=np.float32)
+        sample_off = np.ascontiguousarray(sample_off, dtype=np.int64)
+        n = len(sample_off) - 1
+        fo = frame_offsets(self.cfg, sample_off)
+        spec = np.zeros((int(fo[-1]), self.bin_max), np.float32)
+        fo2 = np.zeros(n + 1, np.int64)
+        check(self.ctx.lib.srx_partial_dft_batch(self.ctx.h, self.h, _ptr(samples), _ptr(sample_off), n, _ptr(spec), _ptr(fo2)),
+              self.ctx.h)
+        return spec, fo
+
     def write_features_dev(self, samples_d, sample_off_d, n_utt, frame_off_d, total_frames, scale_d, ceps_d):
         check(self.ctx.lib.srx_mfcc_batch_dev(self.ctx.h, self.h, samples_d.ptr, sample_off_d.ptr, n_utt,
                                               frame_off_d.ptr, total_frames, scale_d.ptr if scale_d else None,

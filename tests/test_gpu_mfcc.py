@@ -176,3 +176,77 @@ def test_features_smoothing_deltas_bit_exact(ctx, oracle, WL):
     m = ~np.isnan(ref)
     assert got[m].tobytes() == ref[m].tobytes()
     assert np.isnan(ref[0, 13:]).all()
+
+
+@pytest.mark.parametrize("wl,bins_ref", [(320, 144), (400, 180)])
+def test_partial_dft_spectrum_stand_alone(ctx, oracle, wl, bins_ref):
+    """a5 on its own (SURVEY.md 8c: "per-frame 144-bin spectrum"): Clip::partial_dft (src/clip.cpp:174-194) of every frame
+    through srx_partial_dft_batch against the oracle's naive f64-trig half-window transform.  Bar: per frame,
+    |a - b| <= 1e-4 * max_k |ref_k| (bins with nothing in them cancel to ~1e-7 of the peak, like the cepstra); measured
+    2e-6.  No pre-emphasis, no normalisation: the transform alone."""
+    hop = 160
+    x = synth.utterance_audio(5, 9000)
+    off = np.array([0, 4000, 9000], np.int64)
+    fb, bm = host.mel_filterbank(7200, 48, wl, 16000)
+    assert bm == bins_ref
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop, normalize=False, preemphasis=False), fb)
+    spec, fo = plan.partial_dft(x, off)
+    assert spec.shape == (int(fo[-1]), bm)
+    ref = []
+    for u in range(2):
+        xu = x[off[u]:off[u + 1]]
+        for f in range(oracle.num_frames(len(xu), wl, hop)):
+            ref.append(oracle.partial_dft(xu[f * hop:f * hop + wl], wl, bm))
+    ref = np.stack(ref)
+    assert ref.shape == spec.shape
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    err = (np.abs(spec - ref) / scale).max()
+    assert err <= 1e-4, err
+    assert err <= 2e-5       # measured margin
+    plan.close()
+
+
+def test_partial_dft_mirror_branch(ctx, oracle):
+    """bin_max > N/2: the mirror branch (src/clip.cpp:177, 186-192) in the stand-alone spectrum."""
+    wl, hop = 64, 32
+    fb, bm = host.mel_filterbank(7200, 6, wl, 12000)
+    assert bm > wl // 2
+    x = synth.utterance_audio(3, 1000)
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop, normalize=False, preemphasis=False), fb)
+    spec, fo = plan.partial_dft(x, np.array([0, 1000], np.int64))
+    ref = np.stack([oracle.partial_dft(x[f * hop:f * hop + wl], wl, bm) for f in range(int(fo[1]))])
+    assert (np.abs(spec - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= 1e-4
+    plan.close()
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("wl", [320, 400])
+def test_mfcc_elementwise_distance_from_1e4_relative(ctx, oracle, wl, path):
+    """How far the cepstra are from the north_star's wording taken ELEMENT-WISE ("within 1e-4 relative"), as numbers.
+    After normalizeVolume (an L2 norm, no 1/N: src/clip.cpp:157-164) the samples are ~1/sqrt(L), the filterbank outputs
+    ~1e-2 and the reference's own `log(x + 1)` (src/utils.hpp:55-60) rounds x + 1 to f32: an ABSOLUTE noise of ~6e-8 on
+    cepstra whose median magnitude is 4e-3 and whose smallest are 1e-6.  Any evaluation order other than the
+    reference's own moves such an element by more than 1e-4 of itself; the exact-f32 matrix-core path (no split
+    operands) shows the same distribution as the split-f16 path, so the distance is the reference's rounding noise, not
+    the matrix cores'.  Measured (tools/mfcc_elementwise.py, 521 frames): 99.3-99.6 % of elements within 1e-4 of
+    themselves, worst 1.5e-2 (|ref| = 2.6e-6); with an absolute floor of 1e-2 under |ref| the worst is 2.4e-5; against
+    1e-2 of the frame's largest cepstrum 3.6e-4; against the frame's largest cepstrum 3.9e-6 (the bar the other tests
+    hold at 1e-4)."""
+    lens = [16000, 23456, 5000]
+    off = np.zeros(len(lens) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    x = np.concatenate([synth.utterance_audio(100 + i, n) for i, n in enumerate(lens)])
+    x[:16000] = (0.5 * np.random.default_rng(1).standard_normal(16000)).clip(-1, 1)
+    fb, _ = host.mel_filterbank(7200, 48, wl, 16000)
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, 160), fb, path)
+    got, _ = plan.write_features(x, off)
+    ref = _oracle_batch(oracle, x, off, wl, 160, fb)
+    d = np.abs(got - ref)
+    frame_scale = np.abs(ref).max(axis=1, keepdims=True)
+    pure = d / np.maximum(np.abs(ref), 1e-30)
+    assert (pure <= 1e-4).mean() >= 0.99                                  # measured 0.993-0.996
+    assert (d / np.maximum(np.abs(ref), 1e-2)).max() <= 1e-4              # measured 2.4e-5: element-wise with an absolute floor
+    assert (d / np.maximum(np.abs(ref), 1e-2 * frame_scale)).max() <= 1e-3   # measured 3.6e-4
+    assert (d / frame_scale).max() <= 1e-5                                # measured 3.9e-6
+    assert d.max() <= 1e-6                                                # absolute: measured 2.5e-7 on cepstra up to 0.1
+    plan.close()
