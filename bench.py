@@ -35,6 +35,15 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: dense BF16/F16 MFMA, ~2.5 PFLOP/s
 PEAK_HBM_GBS = 8000.0
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """One line on stderr per stage (rank 0): the JSON line on stdout stays the only thing there."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def build_workload(n_utt, seed):
     from speechrecognition_amd import host, synth
     x, soff = synth.corpus_audio(n_utt, seed)
@@ -176,10 +185,12 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
             dist.barrier()
         torch.cuda.synchronize()
 
+    progress("training shard resident (%d frames on this rank); warm-up" % T)
     for _ in range(warm):
         shard.iteration(O, A, B, 0.2)
         A, B = B, A
     barrier()
+    progress("training: %d timed iterations" % iters)
     shard.time_collectives = True
     ex.bytes_reduced = 0
     ctx.profile_enable(True)
@@ -298,6 +309,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = host.Context(local, stream.cuda_stream)
 
+    progress("process group up, building the headline workload")
     # ---- workload, resident in HBM ----
     x, soff, ntrs, trs, tieds = build_workload(args.utts, seed=1 + rank)
     fb, _ = host.mel_filterbank(FEND, NFILT, WL, SPS)
@@ -344,9 +356,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    progress("workload resident (%d frames); warm-up" % T)
     for _ in range(args.warmup):
         step(False)
     barrier()
+    progress("timed region: %d steps" % args.steps)
     ctx.profile_enable(True)   # HIP event pairs around every kernel launch, on the launch stream
     t0 = time.perf_counter()
     evs = [step(True) for _ in range(args.steps)]
@@ -375,6 +389,7 @@ def main():
     else:
         dt_max, frames_all = dt, float(T)
 
+    progress("headline done: %.3f ms per step on this rank" % (dt / args.steps * 1e3))
     # ---- the like-for-like precision figure: the f32-input matrix-core kernel on the same batch (not in the headline) ----
     extra = {}
     if args.score_path == "f16x3":
@@ -389,11 +404,14 @@ def main():
                                  "note": "same contraction with f32 inputs (exact f32 products); --score-path f32 makes it the headline path"}
     # ---- free the headline buffers, then the strong-scaling legs over BASELINE configs 3-5 ----
     del emis_d, x_d, ceps_d
+    progress("f32-path figure done; alignment leg (%d utterances / %d ranks)" % (args.align_utts, world))
     if args.align_utts > 0:
         extra["align_config4"] = alignment_leg(ctx, torch, dist, backend, rank, world, args.align_utts, 5)
+    progress("training leg (%d utterances / %d ranks)" % (args.train_utts, world))
     if args.train_utts > 0:
         extra["train_config5"] = training_leg(ctx, torch, dist, backend, rank, world, args.train_utts, args.train_iters, 2)
 
+    progress("legs done")
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
         flop_per_frame = 2.0 * (2 * D + 1) * G * M          # GMM scoring, all states

@@ -9,8 +9,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-static constexpr int NW16 = 8;          // waves per workgroup
-static constexpr int FT_PER_WAVE = 2;   // 32-frame tiles a wave keeps in registers
+#ifndef SRX_NW16
+#define SRX_NW16 8
+#endif
+#ifndef SRX_FT_PER_WAVE
+#define SRX_FT_PER_WAVE 2
+#endif
+#ifndef SRX_F16_WAVES_PER_SIMD
+#define SRX_F16_WAVES_PER_SIMD 2
+#endif
+static constexpr int NW16 = SRX_NW16;                  // waves per workgroup
+static constexpr int FT_PER_WAVE = SRX_FT_PER_WAVE;    // 32-frame tiles a wave keeps in registers
 static constexpr int FRAMES_PER_WG = NW16 * FT_PER_WAVE * 32;
 static constexpr int NT16 = 8;          // padding row tiles after the last slice (>= one LDS chunk + one unrolled step)
 static constexpr int NSLICE = 8;        // row slices = XCDs

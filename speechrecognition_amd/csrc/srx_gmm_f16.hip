@@ -268,7 +268,7 @@ __device__ __forceinline__ void wait_vmcnt_at_most(int n) {
 // instruction).  A CU retires roughly one store instruction per ~100 cycles whatever its width: with one dword per
 // lane the 4 GB emission matrix cost as much as all the MFMAs and did not overlap them.
 template <int MP, int KS, bool WIDE>
-__global__ __launch_bounds__(64 * NW16, 2) void k_gmm_f16(const f16x8 *__restrict__ Bp, int64_t T, const f16x8 *__restrict__ Ap,
+__global__ __launch_bounds__(64 * NW16, SRX_F16_WAVES_PER_SIMD) void k_gmm_f16(const f16x8 *__restrict__ Bp, int64_t T, const f16x8 *__restrict__ Ap,
                                                           int ntiles, int tps, int G, float *__restrict__ out, int64_t st_t,
                                                           int64_t st_g, float *__restrict__ dump) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
