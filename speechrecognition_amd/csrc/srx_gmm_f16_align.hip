@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void k_gmm_exact_align(const unsigned char *__
 // ------------------------------------------------------------------------------------------
 // the contraction
 // ------------------------------------------------------------------------------------------
+#ifndef SRX_ALIGN_SLAB
+#define SRX_ALIGN_SLAB 8    // states per output slab: with 8 the workgroup's LDS is 50 KiB and a third workgroup fits a CU once
+#endif                      // the waves without frames of the resident ones have left (16: 59 KiB, two workgroups)
 static constexpr int NWA = SRX_ALIGN_WAVES;   // waves per workgroup
 #ifdef SRX_ALIGN_EXP_STAMP
 // diagnostic build: cycles (s_memtime) of wave 0 of every workgroup, summed per phase; printed by the launcher
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     typedef F16Cfg<MP> Cfg;
     constexpr int KS2 = 2 * KS;
     constexpr int NST = Cfg::NST, SPT = Cfg::SPT;
-    constexpr int SB = SPT > 16 ? SPT : 16;     // states per output slab
+    constexpr int SB = SPT > SRX_ALIGN_SLAB ? SPT : SRX_ALIGN_SLAB;     // states per output slab
     constexpr int TPS = SB / SPT;               // row tiles per slab
     constexpr int LDR = SB + 1;                 // staging row stride (odd: the transposing writes spread over the banks)
     constexpr int TILE_BYTES = KS2 * 1024;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     constexpr int STAGE_BYTES = 64 * LDR * 4;
     constexpr int STAGE_BASE = 2 * CHUNK_BYTES;
     constexpr int TIED_BASE = STAGE_BASE + NWA * STAGE_BYTES;
-    static_assert(STAGE_BYTES * NWA >= TILE_BYTES, "a fragment fetch past the second chunk buffer must stay inside the allocation");
+    static_assert(STAGE_BYTES * NWA + 256 * 4 >= TILE_BYTES, "a fragment fetch past the second chunk buffer must stay inside the allocation");
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[TIED_BASE + 256 * 4];
     typedef __attribute__((address_space(3))) unsigned char *lds_ptr;
     const lds_ptr lds3 = (lds_ptr)lds_all;
