@@ -202,7 +202,7 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
     dt = time.perf_counter() - t0
     coll = {k: float(np.mean(v)) for k, v in shard.collective_ms().items()}
     kern = {}
-    for k in ("k_gmm_f16_align", "k_viterbi", "k_train_transitions", "k_gather_gid", "em_sort", "em_radix_sort", "k_em_logp_seg",
+    for k in ("k_gmm_f16_align", "k_viterbi", "k_train_transitions", "k_gather_gid", "k_em_csort_hist", "k_em_csort_scan", "k_em_csort_scatter", "k_em_logp_seg",
               "k_em_accum_seg1", "k_em_accum_seg2", "k_em_seg_reduce", "k_em_means", "k_em_finish"):
         ms, n = ctx.profile_query(k)
         if n:

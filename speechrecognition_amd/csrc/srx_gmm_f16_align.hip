@@ -16,7 +16,10 @@
 // lines per frame for the Viterbi wave that reads it), staged per wave through LDS in slabs of 64 frames x 16 states.
 #include "srx_gmm_f16.h"
 
-static constexpr int SRX_ALIGN_WAVES = 4;   // NWA: waves per workgroup of k_gmm_f16_align (64 frames each, one utterance)
+#ifndef SRX_ALIGN_NWA
+#define SRX_ALIGN_NWA 4
+#endif
+static constexpr int SRX_ALIGN_WAVES = SRX_ALIGN_NWA;   // NWA: waves per workgroup of k_gmm_f16_align (64 frames each, one utterance)
 
 struct srx_align_plan {
     srx_ctx *ctx = nullptr;
@@ -245,6 +248,11 @@ static __device__ unsigned long long g_stamp[8];
 #define SRX_STAMP(k) do { } while (0)
 #endif
 static constexpr int NTA = 2;                 // row tiles per LDS chunk (two accumulator sets swap roles from tile to tile)
+#ifndef SRX_ALIGN_RING
+#define SRX_ALIGN_RING 1    // 1: three single-tile LDS buffers, DMA two tiles ahead, one barrier per tile; 0: two 2-tile chunk buffers
+#endif
+static constexpr bool RINGA = SRX_ALIGN_RING != 0;
+static constexpr int NBUFA = 3;
 
 __device__ __forceinline__ void align_wait_vmcnt_at_most(int n) {   // s_waitcnt takes an immediate; n is wave-uniform
     switch (n) {
@@ -308,9 +316,9 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     constexpr int NPIECE = NTA * KS2;           // 1 KiB DMA pieces per chunk
     // LDS: [chunk buffer 0][chunk buffer 1][per-wave staging 64 x LDR floats][tied ids of the utterance's states]
     constexpr int STAGE_BYTES = 64 * LDR * 4;
-    constexpr int STAGE_BASE = 2 * CHUNK_BYTES;
+    constexpr int STAGE_BASE = RINGA ? NBUFA * TILE_BYTES : 2 * CHUNK_BYTES;
     constexpr int TIED_BASE = STAGE_BASE + NWA * STAGE_BYTES;
-    static_assert(STAGE_BYTES * NWA + 256 * 4 >= TILE_BYTES, "a fragment fetch past the second chunk buffer must stay inside the allocation");
+    static_assert(RINGA || STAGE_BYTES * NWA + 256 * 4 >= TILE_BYTES, "a fragment fetch past the second chunk buffer must stay inside the allocation");
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[TIED_BASE + 256 * 4];
     typedef __attribute__((address_space(3))) unsigned char *lds_ptr;
     const lds_ptr lds3 = (lds_ptr)lds_all;
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
             for (int s = 0; s < KS2; s++) Bf[f][s] = bsrc[(f * KS2 + s) * 64];
     }
     s_tied[tid] = tied_mine;
+    for (int s_ = tid + 64 * NWA; s_ < S; s_ += 64 * NWA) s_tied[s_] = tied[s0 + s_];   // (workgroups narrower than 256 threads)
     __syncthreads();
     // waves of this workgroup that have frames (a finished wave no longer counts at the barriers below)
     SRX_STAMP(0);   // item lookup, tied ids into LDS, barrier
@@ -380,7 +389,21 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
                                              (__attribute__((address_space(3))) void *)(lds_all + buf * CHUNK_BYTES + p * 1024), 16, 0, 0);
         }
     };
-    dma(0, 0);
+    // ring form: one tile per buffer
+    auto dma_tile = [&](int n, int buf) __attribute__((always_inline)) {
+        int sl = n * SPT + sl_lane;
+        sl = sl < S ? sl : S - 1;
+        const f16x8 *src = Alane + (int64_t)s_tied[sl] * STATE_STRIDE;
+        for (int p = w; p < KS2; p += nwa)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * MP * 2),
+                                             (__attribute__((address_space(3))) void *)(lds_all + buf * TILE_BYTES + p * 1024), 16, 0, 0);
+    };
+    if (RINGA) {
+        dma_tile(0, 0);
+        dma_tile(1, 1);      // ntile_r >= 2
+    } else {
+        dma(0, 0);
+    }
 
     // ---- this wave's frames: B' fragments from the plan's cache (loads issued above), or built in place (k_prep16's
     // routine); kept in registers for the whole kernel ----
@@ -454,6 +477,56 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     };
 
     f16x8 AfA[KS2], AfB[KS2];
+    // One row tile n (fragments Afc, LDS offset of the NEXT tile's first fragment in nxt0): its MFMAs write `acc` while the
+    // epilogue of tile n-1 reads `accp` and the fragments of the next tile are fetched into Afn, one ds_read_b128 per MFMA gap.
+    auto do_tile = [&](int n, unsigned nxt0, f32x16 (&acc)[FT_PER_WAVE], const f32x16 (&accp)[FT_PER_WAVE], const f16x8 (&Afc)[KS2],
+                       f16x8 (&Afn)[KS2]) __attribute__((always_inline)) {
+        unsigned nxt = nxt0;
+        static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int p = i / (KS * FT_PER_WAVE), s_ = (i / FT_PER_WAVE) % KS, f = i % FT_PER_WAVE;
+            const f16x8 a_ = p == 0 ? Afc[KS + s_] : Afc[s_];
+            const f16x8 b_ = p == 1 ? Bf[f][KS + s_] : Bf[f][s_];
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, i < FT_PER_WAVE ? z : acc[f], 0, 0, 0);
+            if constexpr (i >= 1 && i <= KS2) {
+                asm volatile("" : "+v"(nxt));
+                Afn[i - 1 < KS ? KS + i - 1 : i - 1 - KS] = frag(nxt, i - 1);
+            }
+            epi_slice(ic, accp, n - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (n >= 1 && (n - 1) % TPS == TPS - 1) flush_slab((n - 1) / TPS);   // tile n-1 closed a slab
+    };
+    if (RINGA) {
+        // Tile n sits in buffer n % 3.  At the barrier in front of tile n the pieces of tiles n and n+1 have landed (a wave
+        // waits for its own pieces of n+1, issued one tile ago: in flight, oldest first, are [pieces of n+1][stores since], so
+        // waiting until at most that many operations are outstanding leaves the stores in flight), so the fragments of tile
+        // n+1 can be fetched under tile n's MFMAs; the buffer of tile n-1 is free for the DMA of tile n+2.
+        auto ring_step = [&](int n, f32x16 (&acc)[FT_PER_WAVE], const f32x16 (&accp)[FT_PER_WAVE], const f16x8 (&Afc)[KS2],
+                             f16x8 (&Afn)[KS2]) __attribute__((always_inline)) {
+            if (n == 0 || pend_stores < 0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+                align_wait_vmcnt_at_most(pend_stores);
+            __syncthreads();
+            if (n == 0) SRX_STAMP(1);
+            if (n + 2 < ntile_r) dma_tile(n + 2, (n + 2) % NBUFA);
+            pend_stores = 0;
+            do_tile(n, ((n + 1) % NBUFA) * TILE_BYTES + lane * 16, acc, accp, Afc, Afn);
+        };
+        for (int n = 0; n < ntile_r; n += 2) {
+            if (n == 0) {
+                // (the first tile's own fragments: after its barrier; everything later arrives under the previous tile)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < KS2; q++) AfA[q < KS ? KS + q : q - KS] = frag(lane * 16, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ring_step(n, accA, accB, AfA, AfB);
+            ring_step(n + 1, accB, accA, AfB, AfA);
+        }
+    } else {
     for (int c = 0; c < nchunks; c++) {
         // This wave's DMA pieces of chunk c must have landed.  In flight, oldest first: [pieces of chunk c][stores issued
         // since].  vmcnt retires in order, so waiting until at most that many operations are outstanding waits for the
@@ -467,35 +540,15 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
         if (c + 1 < nchunks) dma(c + 1, (c + 1) & 1);
         pend_stores = 0;
         const unsigned cb = (c & 1) * CHUNK_BYTES + lane * 16;   // this lane's 16 bytes of the chunk's first fragment
-        // One row tile n = c*NTA + tt: its MFMAs (fragments Afc) write `acc` while the epilogue of tile n-1 reads `accp`
-        // and the fragments of the next tile of the chunk are fetched into Afn, one ds_read_b128 per MFMA gap.  After the
-        // last tile of a chunk the fetch reads past the chunk -- still inside this workgroup's LDS -- and is not used: the
-        // first tile of a chunk is read again after the barrier.
-        auto do_tile = [&](int tt, f32x16 (&acc)[FT_PER_WAVE], const f32x16 (&accp)[FT_PER_WAVE], const f16x8 (&Afc)[KS2],
-                           f16x8 (&Afn)[KS2]) __attribute__((always_inline)) {
-            const int n = c * NTA + tt;
-            unsigned nxt = cb + (tt + 1) * TILE_BYTES;
-            static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                constexpr int p = i / (KS * FT_PER_WAVE), s_ = (i / FT_PER_WAVE) % KS, f = i % FT_PER_WAVE;
-                const f16x8 a_ = p == 0 ? Afc[KS + s_] : Afc[s_];
-                const f16x8 b_ = p == 1 ? Bf[f][KS + s_] : Bf[f][s_];
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, i < FT_PER_WAVE ? z : acc[f], 0, 0, 0);
-                if constexpr (i >= 1 && i <= KS2) {
-                    asm volatile("" : "+v"(nxt));
-                    Afn[i - 1 < KS ? KS + i - 1 : i - 1 - KS] = frag(nxt, i - 1);
-                }
-                epi_slice(ic, accp, n - 1);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if (n >= 1 && (n - 1) % TPS == TPS - 1) flush_slab((n - 1) / TPS);   // tile n-1 closed a slab
-        };
+        // After the last tile of a chunk the fragment fetch reads past the chunk -- still inside this workgroup's LDS -- and is
+        // not used: the first tile of a chunk is read again after the barrier.
 #pragma unroll
         for (int n = 0; n < KS2; n++) AfA[n < KS ? KS + n : n - KS] = frag(cb, n);
         __builtin_amdgcn_sched_barrier(0);
         static_assert(NTA == 2, "two tiles per chunk: accumulator and fragment sets alternate A, B");
-        do_tile(0, accA, accB, AfA, AfB);
-        do_tile(1, accB, accA, AfB, AfA);
+        do_tile(c * NTA, cb + TILE_BYTES, accA, accB, AfA, AfB);
+        do_tile(c * NTA + 1, cb + 2 * TILE_BYTES, accB, accA, AfB, AfA);
+    }
     }
     SRX_STAMP(2);   // the tile loop
     static_for16(std::make_integer_sequence<int, NMF>{}, [&](auto ic) __attribute__((always_inline)) { epi_slice(ic, accB, ntile_r - 1); });

@@ -219,7 +219,7 @@ extern "C" int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
 }
 
 // srx_train_seg.hip: sort-by-state segmented reduction for tables beyond LDS
-bool srx_em_seg_applicable(int M, int D);
+bool srx_em_seg_applicable(int G, int M, int D);
 int srx_em_logp_seg(srx_ctx *ctx, const float *feats, int ld, int64_t T, int G, int M, int D, const double *mean, const double *rvar,
                     const double *lconst, const float *logwt, float *logp, float *shift);
 int srx_em_seg_sort(srx_ctx *ctx, const int32_t *gid, int64_t T, int G);
@@ -240,7 +240,7 @@ extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
     if (T == 0) return SRX_OK;
     // tables beyond LDS: the passes of this alignment run as a segmented reduction over frames sorted by state; the
     // sort belongs to the alignment, and this is the first step every iteration takes with a new one
-    const bool seg = (size_t)A->G * A->M * (1 + A->D) * sizeof(double) > 64 * 1024 && srx_em_seg_applicable(A->M, A->D);
+    const bool seg = (size_t)A->G * A->M * (1 + A->D) * sizeof(double) > 64 * 1024 && srx_em_seg_applicable(A->G, A->M, A->D);
     if (seg) {
         int rc = srx_em_seg_sort(ctx, gid_dev, T, A->G);
         if (rc != SRX_OK) return rc;
@@ -288,7 +288,7 @@ static int launch_accum(srx_ctx *ctx, srx_model *A, srx_model *B, const float *f
             hipLaunchKernelGGL((k_em_accum<PASS, true>), dim3((unsigned)nb), dim3(256), bytes, ctx->stream, feats, ld, gid, T, A->M, A->D,
                                nrows, A->weight, logp, shift, meanB, stats);
         }
-    } else if (srx_em_seg_applicable(A->M, A->D)) {
+    } else if (srx_em_seg_applicable(A->G, A->M, A->D)) {
         return srx_em_accum_seg<PASS>(ctx, feats, ld, gid, T, A->G, A->M, A->D, A->weight, logp, shift, meanB, stats);
     } else {
         {

@@ -2,8 +2,8 @@
 // accumulation of srx_train.hip, i.e. BASELINE shapes: G*M = 32,000 rows of 1+D doubles = 10 MB).
 //
 // Replaces the same reference loops as k_em_accum (hmm::train passes, src/hmm.cpp:298-339).  Frames are sorted by
-// tied state once per iteration (stable radix sort: within a state they stay in frame order, so sums are
-// deterministic -- no atomics anywhere); a workgroup then owns up to CH consecutive frames of ONE state and keeps
+// tied state once per iteration (a stable counting sort written here: within a state they stay in frame order, so
+// sums are deterministic -- no atomics anywhere); a workgroup then owns up to CH consecutive frames of ONE state and keeps
 // that state's M x D sums in registers while the frames' zetas and feature rows pass through LDS (pass 2: the squared
 // f32 difference to the new mean depends on component AND column, so it is no matrix product; an LDS-free form with
 // one wave per item and 128-bit row loads was measured at 10.8 ms against this form's 9.1 -- the f64 <-> f32 conversions
@@ -12,8 +12,6 @@
 // chunk order by a second small kernel.
 // At G = 2000, M = 16, D = 39 the HBM-atomics form spends 157 ms per pass on 5e6 frames; this form is bound by
 // reading logp and the feature rows once.
-#include <hipcub/hipcub.hpp>
-
 #include "srx_common.h"
 
 // exp(y) in f64 for the zeta of the accumulation passes (y = logp - shift: at most a little above 0, down to -inf).
@@ -45,44 +43,182 @@ __device__ __forceinline__ double srx_exp_f64(double y) {
 static constexpr int CH = 2048;     // frames per work item
 static constexpr int FB = 32;       // frames staged per step
 
+static constexpr int CS_CHUNK = 4096;   // frames per wave of the counting sort
+static constexpr int CS_GROUP = 64;     // chunks per group of the two-level scan
+
 struct EmSortView {
-    int32_t *keys_in, *keys_out, *vals_in, *order;   // [T] each; order = frame indices sorted by state
-    int64_t *start;                                  // [G+2] first sorted position of state g; start[G] = aligned frames
-    int32_t *item_start;                             // [G+1] exclusive scan of ceil(n_g / CH)
+    int32_t *order;       // [T] frame indices sorted by state (skipped frames, gid < 0, last)
+    int32_t *hist;        // [n_chunks][G+1] per-chunk key counts, then (in place) each chunk's offset inside its group of chunks
+    int32_t *gsum;        // [n_groups][G+1] per-group key counts, then (in place) each group's offset inside its key's segment
+    int64_t *total;       // [G+1] frames per key
+    int64_t *start;       // [G+2] first sorted position of state g; start[G] = aligned frames; start[G+1] = T
+    int32_t *item_start;  // [G+1] exclusive scan of ceil(n_g / CH)
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+static int64_t cs_chunks(int64_t T) { return (T + CS_CHUNK - 1) / CS_CHUNK; }
 
 static void em_sort_view(void *base, int64_t T, int G, EmSortView *v) {
     char *p = reinterpret_cast<char *>(base);
-    v->keys_in = reinterpret_cast<int32_t *>(p);  p += align256((size_t)T * 4);
-    v->keys_out = reinterpret_cast<int32_t *>(p); p += align256((size_t)T * 4);
-    v->vals_in = reinterpret_cast<int32_t *>(p);  p += align256((size_t)T * 4);
     v->order = reinterpret_cast<int32_t *>(p);    p += align256((size_t)T * 4);
+    v->hist = reinterpret_cast<int32_t *>(p);     p += align256((size_t)cs_chunks(T) * (G + 1) * 4);
+    v->gsum = reinterpret_cast<int32_t *>(p);     p += align256((size_t)(cs_chunks(T) / 64 + 1) * (G + 1) * 4);
+    v->total = reinterpret_cast<int64_t *>(p);    p += align256((size_t)(G + 2) * 8);
     v->start = reinterpret_cast<int64_t *>(p);    p += align256((size_t)(G + 2) * 8);
     v->item_start = reinterpret_cast<int32_t *>(p);
 }
-static size_t em_sort_bytes(int64_t T, int G) { return 4 * align256((size_t)T * 4) + align256((size_t)(G + 2) * 8) + align256((size_t)(G + 2) * 4); }
-
-__global__ __launch_bounds__(256) void k_em_sort_keys(const int32_t *__restrict__ gid, int64_t T, int G, int32_t *__restrict__ keys,
-                                                      int32_t *__restrict__ vals) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    const int g = gid[t];
-    keys[t] = (g < 0 || g >= G) ? G : g;   // skipped frames sort last
-    vals[t] = (int32_t)t;
+static size_t em_sort_bytes(int64_t T, int G) {
+    return align256((size_t)T * 4) + align256((size_t)cs_chunks(T) * (G + 1) * 4) + align256((size_t)(cs_chunks(T) / 64 + 1) * (G + 1) * 4) +
+           2 * align256((size_t)(G + 2) * 8) + align256((size_t)(G + 2) * 4);
 }
 
-// start[g] = first sorted position whose key >= g, g = 0 .. G (start[G] = number of aligned frames)
-__global__ __launch_bounds__(256) void k_em_seg_bounds(const int32_t *__restrict__ keys, int64_t T, int G, int64_t *__restrict__ start) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > G) return;
-    int64_t lo = 0, hi = T;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < g) lo = mid + 1; else hi = mid;
+// ---- stable counting sort of the frame indices by tied state -------------------------------------------------------
+// Keys are 0 .. G (G = "skipped": gid < 0 or out of range); a Viterbi path stays in a state for a dozen frames, so the
+// 64 keys a wave looks at hold a handful of distinct values.  A wave owns CS_CHUNK consecutive frames and walks them 64
+// at a time; the lanes that share a key are found with one ballot per distinct key (no atomics: the first lane of a
+// key group updates the LDS counter for the whole group), which also gives a lane its rank inside the group -- so the
+// scatter is stable.  Pass 1 counts per (chunk, key); a scan over the chunks of a key and then over the keys turns the
+// counts into positions; pass 2 re-reads the keys and writes the indices.
+__device__ __forceinline__ int cs_key(const int32_t *__restrict__ gid, int64_t t, int G) {
+    const int g = gid[t];
+    return (g < 0 || g >= G) ? G : g;
+}
+
+// for the lanes in `valid`: cnt = lanes of the wave with this lane's key, rank = those among them below this lane,
+// leader = this lane is the lowest of its group
+__device__ __forceinline__ void cs_match(int key, unsigned long long valid, int lane, int &cnt, int &rank, bool &leader) {
+    unsigned long long remaining = valid;
+    cnt = 0; rank = 0; leader = false;
+    while (remaining) {
+        const int l0 = __builtin_ctzll(remaining);
+        const int k0 = __shfl(key, l0, 64);
+        const unsigned long long m = __ballot(key == k0) & valid;
+        if (key == k0 && ((valid >> lane) & 1ull)) {
+            cnt = __builtin_popcountll(m);
+            rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            leader = lane == l0;
+        }
+        remaining &= ~m;
     }
-    start[g] = lo;
+}
+
+__global__ __launch_bounds__(64) void k_em_csort_hist(const int32_t *__restrict__ gid, int64_t T, int G, int32_t *__restrict__ hist) {
+    extern __shared__ int32_t cs_h[];   // [G+1]
+    const int lane = threadIdx.x, Gp = G + 1;
+    const int64_t c = blockIdx.x, t0 = c * CS_CHUNK;
+    for (int i = lane; i < Gp; i += 64) cs_h[i] = 0;
+    __syncthreads();
+    const int64_t t1 = t0 + CS_CHUNK < T ? t0 + CS_CHUNK : T;
+    for (int64_t tb = t0; tb < t1; tb += 64) {
+        const int64_t t = tb + lane;
+        const bool v = t < t1;
+        const int key = v ? cs_key(gid, t, G) : -1;
+        int cnt, rank;
+        bool leader;
+        cs_match(key, __ballot(v), lane, cnt, rank, leader);
+        if (leader) cs_h[key] += cnt;      // distinct keys per leader: no two lanes touch one counter
+    }
+    __syncthreads();
+    for (int i = lane; i < Gp; i += 64) hist[c * Gp + i] = cs_h[i];
+}
+
+// Two-level scan over the chunks of a key (a single serial walk over 12,000 chunks per key took 3.6 ms):
+//   a) thread (key, group of CS_GROUP chunks): hist[c][g] <- number of key-g frames in the group's chunks before c;
+//      gsum[group][g] = the group's total (loads first, then the prefix, then the stores: nothing waits on a store);
+//   b) thread (key): gsum[group][g] <- frames in groups before it; total[g] = all of them.
+__global__ __launch_bounds__(256) void k_em_csort_scan_a(int32_t *__restrict__ hist, int64_t n_chunks, int Gp, int32_t *__restrict__ gsum) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= Gp) return;
+    const int64_t q = blockIdx.y, c0 = q * CS_GROUP;
+    int32_t v[CS_GROUP];
+#pragma unroll
+    for (int i = 0; i < CS_GROUP; i++) v[i] = c0 + i < n_chunks ? hist[(c0 + i) * Gp + g] : 0;
+    int32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < CS_GROUP; i++) {
+        const int32_t x = v[i];
+        v[i] = run;
+        run += x;
+    }
+#pragma unroll
+    for (int i = 0; i < CS_GROUP; i++)
+        if (c0 + i < n_chunks) hist[(c0 + i) * Gp + g] = v[i];
+    gsum[q * Gp + g] = run;
+}
+__global__ __launch_bounds__(256) void k_em_csort_scan_b(int32_t *__restrict__ gsum, int64_t n_groups, int Gp, int64_t *__restrict__ total) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= Gp) return;
+    int64_t run = 0;
+    for (int64_t q0 = 0; q0 < n_groups; q0 += 16) {
+        int32_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = q0 + i < n_groups ? gsum[(q0 + i) * Gp + g] : 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (q0 + i < n_groups) gsum[(q0 + i) * Gp + g] = (int32_t)run;    // < 2^31: T is
+            run += v[i];
+        }
+    }
+    total[g] = run;
+}
+
+// start[g] = sum of total[0 .. g), g = 0 .. G+1 (one block; G is at most a few tens of thousands)
+__global__ __launch_bounds__(1024) void k_em_csort_starts(const int64_t *__restrict__ total, int Gp, int64_t *__restrict__ start) {
+    __shared__ int64_t part[1024];
+    const int per = (Gp + 1023) / 1024;
+    const int g0 = threadIdx.x * per;
+    int64_t s = 0;
+    for (int g = g0; g < g0 + per && g < Gp; g++) s += total[g];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int64_t run = part[threadIdx.x] - s;
+    for (int g = g0; g < g0 + per && g < Gp; g++) {
+        start[g] = run;
+        run += total[g];
+    }
+    if (threadIdx.x == 1023) start[Gp] = part[1023];
+}
+
+__global__ __launch_bounds__(64) void k_em_csort_scatter(const int32_t *__restrict__ gid, int64_t T, int G, const int32_t *__restrict__ hist,
+                                                         const int32_t *__restrict__ gsum, const int64_t *__restrict__ start,
+                                                         int32_t *__restrict__ order) {
+    extern __shared__ int32_t cs_h[];   // [G+1] next position of each key (positions are < 2^31)
+    const int lane = threadIdx.x, Gp = G + 1;
+    const int64_t c = blockIdx.x, t0 = c * CS_CHUNK;
+    for (int i = lane; i < Gp; i += 64) cs_h[i] = (int32_t)(start[i] + gsum[(c / CS_GROUP) * Gp + i] + hist[c * Gp + i]);
+    __syncthreads();
+    const int64_t t1 = t0 + CS_CHUNK < T ? t0 + CS_CHUNK : T;
+    for (int64_t tb = t0; tb < t1; tb += 64) {
+        const int64_t t = tb + lane;
+        const bool v = t < t1;
+        const int key = v ? cs_key(gid, t, G) : -1;
+        int cnt, rank;
+        bool leader;
+        cs_match(key, __ballot(v), lane, cnt, rank, leader);
+        int base = 0;
+        if (leader) {
+            base = cs_h[key];
+            cs_h[key] = base + cnt;
+        }
+        // every lane of a group takes the base its leader read: the groups are few, so each leader's (key, base) is
+        // broadcast in turn
+        int my_base = 0;
+        unsigned long long leaders = __ballot(leader);
+        while (leaders) {
+            const int l0 = __builtin_ctzll(leaders);
+            const int k0 = __shfl(key, l0, 64);
+            const int b0 = __shfl(base, l0, 64);
+            if (key == k0) my_base = b0;
+            leaders &= leaders - 1;
+        }
+        if (v) order[my_base + rank] = (int32_t)t;
+    }
 }
 
 // item_start = exclusive scan of ceil(n_g / CH) over states (one block; G is at most a few tens of thousands)
@@ -496,7 +632,8 @@ __global__ __launch_bounds__(256) void k_em_seg_reduce(const int32_t *__restrict
     }
 }
 
-bool srx_em_seg_applicable(int M, int D) { return M <= 16 && D <= 63; }   // 16 components x 64 row elements: 256 threads x at most 4 sums
+// 16 components x 64 row elements: 256 threads x at most 4 sums; the counting sort keeps G + 1 counters in LDS
+bool srx_em_seg_applicable(int G, int M, int D) { return M <= 16 && D <= 63 && G + 1 <= 16384; }
 
 // Sorts the frames of alignment `gid` by state into workspace slot 2 (kept until the next sort).
 int srx_em_seg_sort(srx_ctx *ctx, const int32_t *gid, int64_t T, int G) {
@@ -507,25 +644,26 @@ int srx_em_seg_sort(srx_ctx *ctx, const int32_t *gid, int64_t T, int G) {
     EmSortView v;
     em_sort_view(ws, T, G, &v);
     ctx->em_gid = nullptr;
+    const int Gp = G + 1;
+    const int64_t nch = cs_chunks(T);
+    SRX_REQUIRE(ctx, nch < (1ll << 31), "srx_em_*: too many frames");
+    const size_t lds = (size_t)Gp * sizeof(int32_t);
     {
-        SrxProf prof_(ctx, "k_em_sort_keys");
-        hipLaunchKernelGGL(k_em_sort_keys, dim3((unsigned)ceil_div64(T, 256)), dim3(256), 0, ctx->stream, gid, T, G, v.keys_in, v.vals_in);
+        SrxProf prof_(ctx, "k_em_csort_hist");
+        hipLaunchKernelGGL(k_em_csort_hist, dim3((unsigned)nch), dim3(64), lds, ctx->stream, gid, T, G, v.hist);
     }
     SRX_LAUNCH_CHECK(ctx);
-    int bits = 1;
-    while ((1ll << bits) <= G) bits++;
-    size_t temp_bytes = 0;
-    SRX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, v.keys_in, v.keys_out, v.vals_in, v.order, (int)T, 0, bits, ctx->stream));
-    void *temp = nullptr;
-    rc = srx_workspace(ctx, 3, temp_bytes, &temp);
-    if (rc != SRX_OK) return rc;
     {
-        SrxProf prof_(ctx, "em_radix_sort");
-        SRX_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, v.keys_in, v.keys_out, v.vals_in, v.order, (int)T, 0, bits, ctx->stream));
+        SrxProf prof_(ctx, "k_em_csort_scan");
+        const int64_t ngr = (nch + CS_GROUP - 1) / CS_GROUP;
+        hipLaunchKernelGGL(k_em_csort_scan_a, dim3((Gp + 255) / 256, (unsigned)ngr), dim3(256), 0, ctx->stream, v.hist, nch, Gp, v.gsum);
+        hipLaunchKernelGGL(k_em_csort_scan_b, dim3((Gp + 255) / 256), dim3(256), 0, ctx->stream, v.gsum, ngr, Gp, v.total);
+        hipLaunchKernelGGL(k_em_csort_starts, dim3(1), dim3(1024), 0, ctx->stream, v.total, Gp, v.start);
     }
+    SRX_LAUNCH_CHECK(ctx);
     {
-        SrxProf prof_(ctx, "k_em_seg_bounds");
-        hipLaunchKernelGGL(k_em_seg_bounds, dim3((G + 1 + 255) / 256), dim3(256), 0, ctx->stream, v.keys_out, T, G, v.start);
+        SrxProf prof_(ctx, "k_em_csort_scatter");
+        hipLaunchKernelGGL(k_em_csort_scatter, dim3((unsigned)nch), dim3(64), lds, ctx->stream, gid, T, G, v.hist, v.gsum, v.start, v.order);
     }
     SRX_LAUNCH_CHECK(ctx);
     {

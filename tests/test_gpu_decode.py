@@ -126,3 +126,33 @@ def test_update_states_on_lexicon_transitions(ctx, oracle):
         assert status[u] == r["status"] == 0 and final[u].tobytes() == r["final"].tobytes()
         assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"])
     hmm.close()
+
+
+def test_graph_viterbi_edge_cases(ctx, oracle):
+    """Ragged and degenerate inputs: an empty batch, an utterance of zero frames (NO PATH), one frame, a beam that prunes
+    everything but the best, and the compiled end condition on a lexicon HMM (the path must end in the LAST word's silence)."""
+    rng = np.random.default_rng(9)
+    words, uni = _lexicon(rng, 12)
+    a = host.build_lexicon_hmm(words, uni)
+    tied = a["ctx"][:, 1].copy()
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    emis, _ = _emissions_for(rng, a, words, 6, 2)
+    emis_d = ctx.array(emis)
+    p, f, s, st = hmm.viterbi(emis_d, G, 1, np.array([0], np.int64), 1e10, 1)          # no utterances
+    assert len(st) == 1 and len(f) == 1                                               # (buffers are padded to one element; untouched)
+    T = len(emis)
+    fo = np.array([0, 0, 1, 1, T], np.int64)                                           # T = 0, 1, 0, T-1
+    for final_mode in (0, 1):
+        for beam in (1e10, 0.0):
+            p, f, s, st = hmm.viterbi(emis_d, G, 1, fo, beam, final_mode)
+            for u in range(4):
+                e = emis[fo[u]:fo[u + 1]]
+                if len(e) == 0:
+                    assert st[u] == 1                                                  # nothing to decode: the reference's curr holds only the start state
+                    continue
+                r = oracle.viterbi_graph(e, tied, a["tr_off"], a["tr_tgt"], a["tr_logp"], beam, 0, final_mode)
+                assert st[u] == r["status"], (final_mode, beam, u)
+                if r["status"] == 0:
+                    assert f[u].tobytes() == r["final"].tobytes() and s[u] == r["final_state"]
+                    assert np.array_equal(p[fo[u]:fo[u + 1]], r["path"])
+    hmm.close()

@@ -89,7 +89,7 @@ def main():
     out["training_iteration_ms"] = timed(lambda: shard.iteration(A, A, B, 0.2))
     kern = {}
     for k in ("k_gmm_f16_align", "k_viterbi", "k_train_transitions", "k_gather_gid", "k_fill_f32", "k_em_logp", "k_em_accum1",
-              "k_em_means", "k_em_accum2", "k_em_finish", "k_em_sort_keys", "em_radix_sort", "k_em_seg_bounds",
+              "k_em_means", "k_em_accum2", "k_em_finish", "k_em_csort_hist", "k_em_csort_scan", "k_em_csort_scatter",
               "k_em_item_scan", "k_em_logp_seg", "k_em_logp_skipped", "k_em_accum_seg1", "k_em_accum_seg2", "k_em_seg_reduce"):
         ms, n = ctx.profile_query(k)
         if n:
