@@ -27,6 +27,7 @@
 // is blockIdx.x % 8, i.e. its XCD under round-robin placement, so each XCD's L2 holds "its" 1/8 of A' (1.25 MB at
 // 2000 x 16 x 39) and every chunk after the first comes from L2.  Gaussians are the MFMA rows, frames the columns:
 // a lane's 16 accumulators are the components of whole states for one frame, the mixture log-sum-exp is in-lane.
+#include <atomic>
 #include <cmath>
 
 #include "srx_common.h"
@@ -164,7 +165,10 @@ int ensure_packed16(srx_ctx *ctx, srx_model *m, int mix_mode, int KS) {
     }
     auto adopt = [&]() -> int {
         SRX_HIP(ctx, hipMemcpyAsync(m->colstats, m->colstats + 3 * D, 3 * (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-        m->colstats_epoch++;
+        // epochs are unique across models (a plan's frame-operand cache is keyed on the epoch: a model freed and another
+        // allocated at its address must not look like the same centre / scale vector)
+        static std::atomic<uint64_t> next_epoch{1};
+        m->colstats_epoch = next_epoch.fetch_add(1);
         return SRX_OK;
     };
     if (!keep) {
