@@ -492,7 +492,11 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
                 asm volatile("" : "+v"(nxt));
                 Afn[i - 1 < KS ? KS + i - 1 : i - 1 - KS] = frag(nxt, i - 1);
             }
+#ifdef SRX_ALIGN_EXP_NOEPI
+            if constexpr (i == NMF - 1) stage[lane * LDR] = accp[0][0] + accp[FT_PER_WAVE - 1][15];   // diagnostic build: MFMAs only
+#else
             epi_slice(ic, accp, n - 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         if (n >= 1 && (n - 1) % TPS == TPS - 1) flush_slab((n - 1) / TPS);   // tile n-1 closed a slab
