@@ -22,17 +22,17 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
         atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
 
+// one workgroup per utterance: its frames' path states -> tied ids (-1 for an utterance without a path).  (One thread per frame with
+// a binary search over the frame offsets was 17 dependent loads per frame at 100,000 utterances: 0.67 ms per 5e7 frames.)
 __global__ __launch_bounds__(256) void k_gather_gid(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                                     const int32_t *__restrict__ tied, const int32_t *__restrict__ path,
                                                     const int32_t *__restrict__ status, int64_t total, int32_t *__restrict__ gid) {
-    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= total) return;
-    int lo = 0, hi = n_utt;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (foff[mid] <= f) lo = mid; else hi = mid;
-    }
-    gid[f] = status[lo] == 0 ? tied[soff[lo] + path[f]] : -1;
+    const int u = blockIdx.x;
+    if (u >= n_utt) return;
+    const int64_t f0 = foff[u], f1 = foff[u + 1] < total ? foff[u + 1] : total;
+    const int s0 = soff[u];
+    const bool ok = status[u] == 0;
+    for (int64_t f = f0 + threadIdx.x; f < f1; f += 256) gid[f] = ok ? tied[s0 + path[f]] : -1;
 }
 
 __global__ void k_fill_f32(float *p, float v, int n) {
@@ -211,7 +211,7 @@ extern "C" int srx_em_gather_gid_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
     if (total_frames == 0 || hmm->n_utt == 0) return SRX_OK;
     {
         SrxProf prof_(ctx, "k_gather_gid");
-        hipLaunchKernelGGL(k_gather_gid, dim3((unsigned)ceil_div64(total_frames, 256)), dim3(256), 0, ctx->stream, hmm->n_utt,
+        hipLaunchKernelGGL(k_gather_gid, dim3((unsigned)hmm->n_utt), dim3(256), 0, ctx->stream, hmm->n_utt,
                            hmm->frame_off_dev, hmm->state_off_dev, hmm->tied_dev, path_dev, status_dev, total_frames, gid_dev);
     }
     SRX_LAUNCH_CHECK(ctx);
