@@ -627,7 +627,15 @@ __global__ __launch_bounds__(256) void k_em_seg_reduce(const int32_t *__restrict
     const int i0 = item_start[g], i1 = item_start[g + 1];
     for (int idx = threadIdx.x; idx < R; idx += 256) {
         double s = 0.0;
-        for (int it = i0; it < i1; it++) s += partial[(size_t)it * R + idx];
+        int it = i0;
+        for (; it + 8 <= i1; it += 8) {   // eight loads in flight, summed in chunk order
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = partial[(size_t)(it + k) * R + idx];
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += v[k];
+        }
+        for (; it < i1; it++) s += partial[(size_t)it * R + idx];
         stats[(size_t)g * R + idx] = s;
     }
 }
