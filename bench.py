@@ -200,7 +200,7 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
     O.set(*synth.random_model(G, M, D, 777))
     A.copy_from(O)
     B.copy_from(O)
-    ex = parallel.Exchange()
+    ex = parallel.Exchange(force=os.environ.get("SRX_BENCH_FORCE_GROUP", "0") == "1")
     shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, ex, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3, emissions="compact")
 
     def barrier():
@@ -310,9 +310,15 @@ def main():
     backend = os.environ.get("SRX_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local %= max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # SRX_BENCH_FORCE_GROUP=1: a process group (and live all-reduces) even with one rank -- the rehearsal of the RCCL code
+    # path of the N>1 run (device tensors, collectives on the context's stream, event pairs) on a one-GPU box
+    force_group = os.environ.get("SRX_BENCH_FORCE_GROUP", "0") == "1"
+    if world > 1 or force_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))

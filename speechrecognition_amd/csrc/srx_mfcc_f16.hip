@@ -233,9 +233,17 @@ __global__ __launch_bounds__(64 * NW, 2) void k_mfcc_f16(Mfcc16Args a) {
         float C0;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
+#ifdef SRX_MFCC_EXP_COAL
+            // diagnostic build (results are wrong): the same number of loads and bytes, but each instruction reads 1 KiB of
+            // consecutive samples instead of 64 pieces 640 bytes apart -- what the per-lane line requests cost
+            const float *src = a.x + ((int64_t)w * 2 * KS + 2 * s) * 256 + lane * 4;
+            A[s] = *reinterpret_cast<const f4u *>(src);
+            B[s] = *reinterpret_cast<const f4u *>(src + 256);
+#else
             const float *src = xu + p0 + 16 * s + 8 * hh;
             A[s] = *reinterpret_cast<const f4u *>(src);
             B[s] = *reinterpret_cast<const f4u *>(src + 4);
+#endif
         }
         C0 = xu[p0 > 0 ? p0 - 1 : 0];
 #pragma unroll

@@ -541,12 +541,13 @@ static size_t viterbi_words(const srx_hmm_batch *hmm, int spl) {
 
 static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t, int64_t stride_g,
                           const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
-    SRX_REQUIRE(ctx, hmm && emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
+    SRX_REQUIRE(ctx, hmm && hmm->n_utt >= 0, "srx_viterbi_batch_dev: null or negative batch");
+    if (hmm->n_utt == 0) return SRX_OK;   // an empty corpus: the reference's `for i < ut.size()` does nothing (src/hmm.cpp:258)
+    SRX_REQUIRE(ctx, emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
     SRX_REQUIRE(ctx, hmm->frame_off_dev && hmm->state_off_dev && hmm->tied_dev && hmm->ntr_dev && hmm->trlogp_dev,
                 "srx_viterbi_batch_dev: null hmm field");
-    SRX_REQUIRE(ctx, hmm->n_utt >= 0 && hmm->max_states >= 1 && hmm->max_states <= 256,
+    SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 256,
                 "srx_viterbi_batch_dev: max_states %d outside 1..256", hmm->max_states);
-    if (hmm->n_utt == 0) return SRX_OK;
     const int64_t total_frames = hmm->total_frames;
     SRX_REQUIRE(ctx, total_frames >= 0, "srx_viterbi_batch_dev: negative total_frames");
     const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : 4);
@@ -600,9 +601,10 @@ extern "C" int srx_viterbi_align_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
 extern "C" int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const int32_t *path_dev,
                                          const int32_t *status_dev) {
     SRX_ENTER(ctx, "srx_train_transitions_dev");
-    SRX_REQUIRE(ctx, hmm && path_dev && status_dev, "srx_train_transitions_dev: null argument");
-    SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 256, "srx_train_transitions_dev: max_states outside 1..256");
+    SRX_REQUIRE(ctx, hmm && hmm->n_utt >= 0, "srx_train_transitions_dev: null or negative batch");
     if (hmm->n_utt == 0) return SRX_OK;
+    SRX_REQUIRE(ctx, path_dev && status_dev, "srx_train_transitions_dev: null argument");
+    SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 256, "srx_train_transitions_dev: max_states outside 1..256");
     {
         SrxProf prof_(ctx, "k_train_transitions");
         hipLaunchKernelGGL(k_train_transitions, dim3(hmm->n_utt), dim3(256), 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,

@@ -31,11 +31,12 @@ class Exchange:
     """The collectives of one EM iteration over torch tensors (CUDA tensors under nccl = RCCL, CPU tensors under
     gloo).  world == 1 (or no process group) is a no-op, so the single-GPU path runs the same code."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=False):
+        """force: run the collectives even in a one-rank group (rehearsal of the RCCL path on one GPU)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.bytes_reduced = 0
         # gloo moves CUDA tensors through its own staging at a few hundred KB/s on this stack (18 s per 10 MB): under
         # gloo (the CPU rehearsal of the multi-GPU path) device tensors are staged through host memory here instead

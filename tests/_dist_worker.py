@@ -1,10 +1,11 @@
 """Worker of the world_size-2 tests (tests/test_parallel_cpu.py, tests/test_gpu_parallel.py).  Not collected by
-pytest.  Usage: python tests/_dist_worker.py <cpu|gpu> <workdir>   with RANK / WORLD_SIZE / MASTER_* in the env.
+pytest.  Usage: python tests/_dist_worker.py <cpu|gpu|gpu_rccl> <workdir>   with RANK / WORLD_SIZE / MASTER_* in the env.
 
 cpu: every rank holds a shard of the aligned frames, computes its partial shifted statistics in numpy (the same
      algebra as srx_train.hip) and exchanges them with speechrecognition_amd.parallel.Exchange over gloo.
 gpu: every rank runs parallel.TrainingShard.iteration on its shard through libsrx on cuda:0 (gloo moves the
      CUDA tensors), two iterations with the acm / temp_acm ping-pong.
+gpu_rccl: the same over the "nccl" backend (= RCCL), which needs one GPU per rank: run with one rank, all-reduces forced on.
 Rank r writes <workdir>/out<r>.npz."""
 import os
 import sys
@@ -27,13 +28,19 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rccl = mode == "gpu_rccl"      # the RCCL path itself (device tensors, collectives on the context's stream): one rank per GPU
+    if rccl:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        mode = "gpu"
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from speechrecognition_amd import parallel
     z = np.load(os.path.join(work, "in.npz"))
     G, M, D = [int(v) for v in z["shape"]]
     mean, var, w = z["mean"], z["var"], z["w"]
-    ex = parallel.Exchange()
-    assert ex.active == (world > 1)
+    ex = parallel.Exchange(force=rccl)   # a one-rank RCCL group still runs its all-reduces
+    assert ex.active == (world > 1 or rccl)
     if mode == "cpu":
         feats, gid, frame_off = z["feats"], z["gid"], z["frame_off"]
         costs = np.diff(frame_off)

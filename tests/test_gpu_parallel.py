@@ -72,3 +72,39 @@ def test_training_iteration_world2_matches_single_process_oracle(oracle, tmp_pat
             np.testing.assert_allclose(got_tr[spos:spos + S], hm[u][1], rtol=5e-6, atol=1e-7)
             pos, spos = pos + n, spos + S
     assert outs[0]["mean"].tobytes() == outs[1]["mean"].tobytes()   # identical on every rank
+
+
+def test_rccl_exchange_one_rank_equals_no_exchange(tmp_path):
+    """The exchange as the driver's multi-GPU run performs it -- torch.distributed "nccl" (= RCCL) on device tensors, enqueued
+    on the context's stream between the producer and the consumer kernels -- with the one rank a one-GPU box allows (RCCL
+    refuses two ranks on one device): an all-reduce over one rank is the identity, so two iterations must end with the
+    alignments and statistics of the run without collectives, and the byte count must be the three buffers' per iteration."""
+    rng = np.random.default_rng(33)
+    G, M, D, iters, n_utt = 40, 2, 13, 2, 6
+    phones = [synth.phone_string(rng, n_words=3) for _ in range(n_utt)]
+    lens = rng.integers(120, 300, n_utt)
+    frame_off = np.zeros(n_utt + 1, np.int64)
+    frame_off[1:] = np.cumsum(lens)
+    mean, var, w = synth.random_model(G, M, D, 9)
+    var *= 2.0
+    feats = np.zeros((int(frame_off[-1]), 39), np.float32)
+    for u in range(n_utt):
+        seg = np.sort(rng.integers(0, len(phones[u]), lens[u]))
+        feats[frame_off[u]:frame_off[u + 1], :D] = (mean[phones[u][seg], 0] + rng.standard_normal((lens[u], D)) * 1.2).astype(np.float32)
+    outs = {}
+    for mode in ("gpu", "gpu_rccl"):
+        work = tmp_path / mode
+        work.mkdir()
+        np.savez(work / "in.npz", shape=[G, M, D], mean=mean, var=var, w=w, feats=feats, frame_off=frame_off, iters=iters,
+                 mix_mode=1, emissions="compact", **{"ph%d" % u: phones[u] for u in range(n_utt)})
+        outs[mode] = run_world(mode, work, 1)[0]
+    a, b = outs["gpu"], outs["gpu_rccl"]
+    assert int(a["bytes_reduced"]) == 0
+    assert int(b["bytes_reduced"]) == iters * (G * M * 4 + G * M * (1 + D) * 8 + G * M * D * 8)
+    for k in ("trlogp", "path"):
+        assert a[k].tobytes() == b[k].tobytes(), k
+    # (the statistics of a table this small are summed with LDS atomics, whose order differs from run to run: last bits)
+    for k, tol in (("mean", 1e-12), ("var", 1e-12), ("w", 1e-6)):
+        assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), k
+        ok = ~np.isnan(a[k])
+        np.testing.assert_allclose(b[k][ok], a[k][ok], rtol=tol, atol=0, err_msg=k)
