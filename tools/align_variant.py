@@ -23,7 +23,9 @@ def run(path, n_utt):
         ntr, tr, _ = host.build_training_hmm(ph)
         ntrs.append(ntr); trs.append(tr)
         tieds.append(rng.integers(0, G, len(ph)).astype(np.int32))
-        Ts.append(int(rng.integers(200, 801)))
+        t_ = int(rng.integers(200, 801))
+        q_ = int(os.environ.get("SRX_T_QUANTUM", "0"))     # e.g. 256: every utterance fills whole workgroups (packing bound)
+        Ts.append(max(q_, (t_ + q_ // 2) // q_ * q_) if q_ else t_)
     fo = np.zeros(n_utt + 1, np.int64)
     fo[1:] = np.cumsum(Ts)
     T = int(fo[-1])
@@ -43,6 +45,7 @@ def run(path, n_utt):
         hb.score_align(A, feats_d, D, emis, 1, SRX_SCORE_MFMA_F16X3)
     ms, k = ctx.profile_query("k_gmm_f16_align")
     ctx.close()
+    print("  frames %d, %.4f ns per frame" % (T, ms / k * 1e6 / T))
     return ms / k
 
 
