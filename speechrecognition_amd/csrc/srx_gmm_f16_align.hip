@@ -518,6 +518,17 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
             pend_stores = 0;
             do_tile(n, ((n + 1) % NBUFA) * TILE_BYTES + lane * 16, acc, accp, Afc, Afn);
         };
+#ifdef SRX_ALIGN_EXP_TWICE
+        // diagnostic build: the tile loop runs twice per workgroup (same tiles, same output) -- kernel time minus the normal
+        // build's is the marginal cost of one pass of the loop
+        for (int rep_ = 0; rep_ < 2; rep_++) {
+        if (rep_ == 1) {
+            __syncthreads();
+            dma_tile(0, 0);
+            dma_tile(1, 1);
+            pend_stores = -1;
+        }
+#endif
         for (int n = 0; n < ntile_r; n += 2) {
             if (n == 0) {
                 // (the first tile's own fragments: after its barrier; everything later arrives under the previous tile)
@@ -530,6 +541,9 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
             ring_step(n, accA, accB, AfA, AfB);
             ring_step(n + 1, accB, accA, AfB, AfA);
         }
+#ifdef SRX_ALIGN_EXP_TWICE
+        }
+#endif
     } else {
     for (int c = 0; c < nchunks; c++) {
         // This wave's DMA pieces of chunk c must have landed.  In flight, oldest first: [pieces of chunk c][stores issued
