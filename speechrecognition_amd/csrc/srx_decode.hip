@@ -48,7 +48,7 @@ extern "C" int srx_hmm_build_lexicon(int n_words, const int32_t *phone_off, cons
     if (n_states_out) *n_states_out = n_states;
     if (n_tr_out) *n_tr_out = n_tr;
     if (!tr_off) return SRX_OK;   // counting call
-    if (!tr_tgt || !tr_logp) return srx_fail(nullptr, SRX_ERR_INVALID, "srx_hmm_build_lexicon: null output");
+    if (n_tr > 0 && (!tr_tgt || !tr_logp)) return srx_fail(nullptr, SRX_ERR_INVALID, "srx_hmm_build_lexicon: null output");
     if (n_states >= (1ll << 31) || n_tr >= (1ll << 31)) return srx_fail(nullptr, SRX_ERR_INVALID, "srx_hmm_build_lexicon: too large");
     // the start state: one transition per word, in word order (src/hmm.cpp:108)
     int64_t q = 0, s = 1;

@@ -315,6 +315,19 @@ Clip read_wav(string fname) {
     int32_t data_len;
     std::memcpy(&data_len, h + 4, 4);
     if (nchannels < 1 || (bps != 8 && bps != 16)) throw wavex_bad;
+    // The reference trusts the header (src/wav.cpp:84-88) and reads past what the file holds.  Here a length the file cannot
+    // back is cut to what is there (a truncated file gives the frames it really has; 0xFFFFFFFF, the "unknown length" of
+    // streamed files, reads to the end), so that a header cannot ask for gigabytes.
+    {
+        const long here = std::ftell(in);
+        long remain = 0;
+        if (here >= 0 && std::fseek(in, 0, SEEK_END) == 0) {
+            remain = std::ftell(in) - here;
+            std::fseek(in, here, SEEK_SET);
+        }
+        if (remain < 0) remain = 0;
+        if (data_len < 0 || (long)data_len > remain) data_len = (int32_t)std::min<long>(remain, 0x7fffffffL);
+    }
     const int nframes = data_len / nchannels / (bps / 8);
     if (srx::verbose()) std::cout << "There are " << nframes << " audio frames" << std::endl;
     vector<unsigned char> raw((size_t)data_len);
