@@ -67,8 +67,8 @@ int main(int argc, char **argv) {
                 it->second->gaussians[0].var[i] = 1.0 + 0.01 * g;
             }
         acm.mark_host_dirty();
-        using namespace phone;
-        vector<phone::phone> pron = {SIL, HH, AH, L, OW, SIL, W, ER, L, D, SIL};
+        namespace P = ::phone;   // (clang: after a `using namespace phone`, `phone::` is ambiguous between the namespace and its enum)
+        vector<P::phone> pron = {P::SIL, P::HH, P::AH, P::L, P::OW, P::SIL, P::W, P::ER, P::L, P::D, P::SIL};
         hmm h(pron, &acm);
         printf("nstates %zu\n", h.states.size());
         printf("ntr");
@@ -105,10 +105,10 @@ int main(int argc, char **argv) {
             }
         printf("\n");
         pronlex lx;
-        lx.add("HELLO", {HH, AH, L, OW});
-        lx.add("WORLD", {W, ER, L, D});
-        lx.add("A", {AH});
-        lx.add("LOW", {L, OW});
+        lx.add("HELLO", {P::HH, P::AH, P::L, P::OW});
+        lx.add("WORLD", {P::W, P::ER, P::L, P::D});
+        lx.add("A", {P::AH});
+        lx.add("LOW", {P::L, P::OW});
         unigram_model uni(1000);
         uni.put("HELLO", 50);
         uni.put("WORLD", 20);

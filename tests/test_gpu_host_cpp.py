@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "speechrecognition_amd", "lib")
+if os.environ.get("SRX_TEST_BIN_DIR"):   # e.g. gpurun_tmp/san: the host-sanitized build of tools/build_host_asan.sh
+    LIB = os.path.abspath(os.environ["SRX_TEST_BIN_DIR"])
 SRX = os.path.join(LIB, "srx")
 API_TEST = os.path.join(LIB, "srx_host_api_test")
 
