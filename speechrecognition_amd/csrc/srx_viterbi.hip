@@ -138,8 +138,15 @@ __device__ __forceinline__ bool viterbi_utt(const int u, const int64_t *__restri
     int64_t eoff[SPL];
 #pragma unroll
     for (int q = 0; q < SPL; q++) eoff[q] = COMPACT ? (int64_t)col[q] : (int64_t)col[q] * st_g;
+    uint32_t colb[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; q++) colb[q] = (uint32_t)col[q] * 4u;
     auto emission = [&](const int t, const int q) __attribute__((always_inline)) -> float {
-        if (COMPACT) return erow[(uint32_t)t * (uint32_t)S + (uint32_t)col[q]];
+        // compact block: the row's address is wave-uniform (scalar arithmetic) and the lane adds a 32-bit byte offset, which
+        // is the load's scalar-base + vector-offset form -- no vector instruction per frame for the address
+        // compact block: the row's offset is wave-uniform (scalar arithmetic) and is added to a per-lane base that never changes:
+        // one 64-bit vector add per load instead of an index add and an address computation
+        if (COMPACT) return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(erow + (size_t)((uint32_t)t * (uint32_t)S)) + colb[q]);
         return erow[(int64_t)t * st_t + eoff[q]];
     };
     float er[PF][SPL];
