@@ -19,6 +19,8 @@
 // in registers, neighbour exchange by DPP wave_shr:1, emission scores prefetched PF frames ahead,
 // 2-bit back-pointers packed 16 frames to a word, device-side backtrace with the current state in
 // an SGPR.
+#include <cstdlib>
+
 #include "srx_common.h"
 
 #include <type_traits>
@@ -48,12 +50,20 @@ static constexpr int NEVER = 0x7fffffff;
 // VEC: state-major dense emissions with 16-byte aligned rows (stride_t == 1, stride_g % 4 == 0): a lane fetches four
 // consecutive frames of its state's row per load -- a quarter of the load instructions and of the cache-line lookups
 // (64 lanes read 64 different rows).  The frame loop then starts at the aligned frame at or before the utterance's first.
-static constexpr int BT_CH = 32;   // 16-frame back-pointer groups staged in LDS per backtrace chunk
+// 16-frame back-pointer groups staged in LDS per backtrace chunk.  OCC (waves per SIMD the kernel is compiled for): with
+// one wave per utterance and fewer utterances than wave slots the kernel is one dependent chain per SIMD and wants every
+// register and a deep staging buffer (OCC = 1: ~200 VGPRs, 16 KiB of LDS -- two waves per SIMD at most); with tens of
+// thousands of utterances it is a throughput kernel and four resident waves per SIMD hide each other's latencies (OCC = 4:
+// 128 VGPRs and a few spilled dwords, 4 KiB of LDS): 4.22 -> 2.95 ms for 100,000 utterances / 49.9 M frames.
+template <int OCC>
+struct VitCfg {
+    static constexpr int BT_CH = OCC > 1 ? 8 : 32;
+};
 
 // One utterance with SPL states per lane.  The LDS arrays belong to the kernel (sized for the batch's widest utterance);
 // sl_alloc = 64 * that width is the row stride the back-pointer workspace was laid out with.
 // Returns true (no-beam bodies only) when the utterance has to be run again through the BEAM body: see `mx` below.
-template <int SPL, bool BEAM, int LAY, int PF>
+template <int SPL, bool BEAM, int LAY, int PF, int BT_CH>
 __device__ __forceinline__ bool viterbi_utt(const int u, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                             const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
                                             const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
@@ -466,13 +476,14 @@ __device__ __forceinline__ bool viterbi_utt(const int u, const int64_t *__restri
 
 // One wavefront per utterance.  SPLMAX covers the batch's widest utterance; an utterance that fits fewer states per
 // lane takes the narrower body (half or a quarter of the vector work per frame).
-template <int SPLMAX, bool BEAM, int LAY, int PF>
-__global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
+template <int SPLMAX, bool BEAM, int LAY, int PF, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_viterbi(int n_utt, const int64_t *__restrict__ foff, const int32_t *__restrict__ soff,
                                                 const int32_t *__restrict__ tied, const int32_t *__restrict__ ntr,
                                                 const float *__restrict__ trlogp, const float *__restrict__ emis, int64_t st_t, int64_t st_g,
                                                 const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
                                                 float *__restrict__ final_logp, int32_t *__restrict__ status) {
     constexpr int SLMAX = 64 * SPLMAX;
+    constexpr int BT_CH = VitCfg<OCC>::BT_CH;
     __shared__ int dmin[SLMAX + 2];
     __shared__ int s_ntr[SLMAX];
     __shared__ uint32_t s_bp[BT_CH * SLMAX];
@@ -488,17 +499,17 @@ __global__ __launch_bounds__(64) void k_viterbi(int n_utt, const int64_t *__rest
     }
     bool redo;
     if (SPLMAX >= 2 && S <= 64)
-        redo = viterbi_utt<1, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
+        redo = viterbi_utt<1, BEAM, LAY, PF1, BT_CH>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
                                               dmin, s_ntr, s_bp, SLMAX);
     else if (SPLMAX >= 4 && S <= 128)
-        redo = viterbi_utt<2, BEAM, LAY, PF1>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
+        redo = viterbi_utt<2, BEAM, LAY, PF1, BT_CH>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp, status,
                                               dmin, s_ntr, s_bp, SLMAX);
     else
-        redo = viterbi_utt<SPLMAX, BEAM, LAY, PF>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp,
+        redo = viterbi_utt<SPLMAX, BEAM, LAY, PF, BT_CH>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, beam, bpws, path, final_logp,
                                                   status, dmin, s_ntr, s_bp, SLMAX);
     if (!BEAM && redo) {   // wave-uniform; rare (non-finite or absurdly large scores): the reference's pruning test decides
         __syncthreads();
-        viterbi_utt<SPLMAX, true, LAY, PF>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, 1e10f, bpws, path, final_logp, status,
+        viterbi_utt<SPLMAX, true, LAY, PF, BT_CH>(u, foff, soff, tied, ntr, trlogp, emis, st_t, st_g, ebase, 1e10f, bpws, path, final_logp, status,
                                            dmin, s_ntr, s_bp, SLMAX);
     }
 }
@@ -564,12 +575,18 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     if (rc != SRX_OK) return rc;
     const bool beam = beam_width < 1e10f;
     dim3 grid(hmm->n_utt), block(64);
+    // several times more utterances than the latency build could keep resident (two waves per SIMD): the throughput build
+    // (VitCfg).  Measured cross-over: equal at 3,000-6,000 utterances, -6 % at 10,000, -30 % at 100,000.
+    static const int64_t occ_min = std::getenv("SRX_VIT_OCC_MIN_UTT") ? std::atoll(std::getenv("SRX_VIT_OCC_MIN_UTT")) : 8192;
+    const bool many = hmm->n_utt >= occ_min;
     const bool vec = !ebase_dev && stride_t == 1 && stride_g % 4 == 0 && stride_g >= total_frames &&
                      (reinterpret_cast<uintptr_t>(emis_dev) & 15) == 0;
 #define SRX_VIT(SPLV, BEAMV)                                                                                              \
     do { if (vec) SRX_VIT2(SPLV, BEAMV, 1); else if (ebase_dev) SRX_VIT2(SPLV, BEAMV, 2); else SRX_VIT2(SPLV, BEAMV, 0); } while (0)
 #define SRX_VIT2(SPLV, BEAMV, LAYV)                                                                                       \
-    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, LAYV, (LAYV == 1 ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF)>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
+    do { if (many) SRX_VIT3(SPLV, BEAMV, LAYV, 4); else SRX_VIT3(SPLV, BEAMV, LAYV, 1); } while (0)
+#define SRX_VIT3(SPLV, BEAMV, LAYV, OCCV)                                                                                 \
+    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, LAYV, (LAYV == 1 ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF), OCCV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
                        hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, ebase_dev, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
     auto launch = [&]() {
@@ -583,6 +600,7 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     }
 #undef SRX_VIT
 #undef SRX_VIT2
+#undef SRX_VIT3
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }
