@@ -19,6 +19,10 @@
 #ifndef SRX_ALIGN_NWA
 #define SRX_ALIGN_NWA 4
 #endif
+static constexpr int WBF = 32 * FT_PER_WAVE;            // frames of a wave block (what one wave keeps in registers)
+#ifndef SRX_ALIGN_WPE
+#define SRX_ALIGN_WPE 2                                 // waves per SIMD k_gmm_f16_align is compiled for
+#endif
 static constexpr int SRX_ALIGN_WAVES = SRX_ALIGN_NWA;   // NWA: waves per workgroup of k_gmm_f16_align (64 frames each, one utterance)
 
 struct srx_align_plan {
@@ -69,14 +73,14 @@ extern "C" int srx_align_plan_create(srx_ctx *ctx, const int64_t *frame_off, con
                             (long long)S);
         }
         p->emis_off_host[u + 1] = p->emis_off_host[u] + S * T;
-        for (int64_t f = 0; f < T; f += 64) {
+        for (int64_t f = 0; f < T; f += WBF) {
             wu.push_back(u);
             wf.push_back((int32_t)f);
         }
-        for (int64_t f = 0; f < T; f += 64 * SRX_ALIGN_WAVES) {
+        for (int64_t f = 0; f < T; f += WBF * SRX_ALIGN_WAVES) {
             gu.push_back(u);
             gf.push_back((int32_t)f);
-            gw.push_back((int32_t)(wu.size() - (size_t)((T + 63) / 64) + (size_t)(f / 64)));
+            gw.push_back((int32_t)(wu.size() - (size_t)((T + WBF - 1) / WBF) + (size_t)(f / WBF)));
         }
     }
     p->n_wb = (int64_t)wu.size();
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void k_gmm_exact_align(const unsigned char *__
     const int64_t f0 = foff[u];
     const int T = (int)(foff[u + 1] - f0);
     const int s0 = soff[u], S = soff[u + 1] - s0;
-    const int nf = T - lf0 < 64 ? T - lf0 : 64;
+    const int nf = T - lf0 < WBF ? T - lf0 : WBF;
     unsigned long long mask = nf == 64 ? ~0ull : ((1ull << nf) - 1);
     if (fflag) mask = __ballot(lane < nf && fflag[f0 + lf0 + lane] != 0);
     if (mask == 0) return;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256) void k_prep16_align(const float *__restrict__ 
 
 // CACHED: the wave's B' fragments come from the plan's cache (Bp); otherwise the wave builds them itself.
 template <int MP, int KS, bool CACHED>
-__global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__restrict__ feats, int ld, int D, const float *__restrict__ cs,
+__global__ __launch_bounds__(64 * NWA, SRX_ALIGN_WPE) void k_gmm_f16_align(const float *__restrict__ feats, int ld, int D, const float *__restrict__ cs,
                                                                const f16x8 *__restrict__ Aps, const f16x8 *__restrict__ Bp,
                                                                const int32_t *__restrict__ wg_utt, const int32_t *__restrict__ wg_wb0,
                                                                const int32_t *__restrict__ wg_f0, int64_t n_wg, int64_t n_wb,
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     constexpr int CHUNK_BYTES = NTA * TILE_BYTES;
     constexpr int NPIECE = NTA * KS2;           // 1 KiB DMA pieces per chunk
     // LDS: [chunk buffer 0][chunk buffer 1][per-wave staging 64 x LDR floats][tied ids of the utterance's states]
-    constexpr int STAGE_BYTES = 64 * LDR * 4;
+    constexpr int STAGE_BYTES = WBF * LDR * 4;
     constexpr int STAGE_BASE = RINGA ? NBUFA * TILE_BYTES : 2 * CHUNK_BYTES;
     constexpr int TIED_BASE = STAGE_BASE + NWA * STAGE_BYTES;
     static_assert(RINGA || STAGE_BYTES * NWA + 256 * 4 >= TILE_BYTES, "a fragment fetch past the second chunk buffer must stay inside the allocation");
@@ -357,9 +361,9 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
     // waves of this workgroup that have frames (a finished wave no longer counts at the barriers below)
     SRX_STAMP(0);   // item lookup, tied ids into LDS, barrier
     const int rem = T - gf0;
-    const int nwa = rem >= 64 * NWA ? NWA : (rem + 63) >> 6;
+    const int nwa = rem >= WBF * NWA ? NWA : (rem + WBF - 1) / WBF;
     if (w >= nwa) return;
-    const int lf0 = gf0 + w * 64;
+    const int lf0 = gf0 + w * WBF;
     float *const stage = reinterpret_cast<float *>(lds_all + STAGE_BASE + w * STAGE_BYTES);   // [64 frames][SB states] of this wave
     float *const ob = out + eoff[u];
     const int j = lane & 31, hh = lane >> 5;
@@ -445,9 +449,10 @@ __global__ __launch_bounds__(64 * NWA, 2) void k_gmm_f16_align(const float *__re
         typedef float f4u_ __attribute__((ext_vector_type(4), aligned(4)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float v[SB];
+        const int row = lane < WBF ? lane : 0;       // (one frame tile per wave: the upper half of the lanes has no row)
 #pragma unroll
-        for (int c = 0; c < SB; c++) v[c] = stage[lane * LDR + c];
-        const int lf = lf0 + lane, c0 = sb * SB;
+        for (int c = 0; c < SB; c++) v[c] = stage[row * LDR + c];
+        const int lf = lane < WBF ? lf0 + lane : T, c0 = sb * SB;
 #ifdef SRX_ALIGN_EXP_NOSTORE
         if (lf0 >= 0) return;                    // diagnostic build: no output stores
 #endif
