@@ -184,6 +184,13 @@ void srx_model_destroy(srx_model *m);
 int srx_model_set(srx_model *m, const double *mean, const double *var, const float *weight);
 int srx_model_get(srx_model *m, double *mean, double *var, float *weight);
 int srx_model_copy(srx_model *dst, const srx_model *src); /* acoustic_model(acoustic_model*) src/gmm.cpp:171-175 */
+/* A counter that every call which rewrites the model's parameters advances (srx_model_set, srx_model_copy into it,
+ * srx_em_means_dev / srx_em_finish_dev on it); 0 for a null model.  No counterpart in the reference.  What it is for: the
+ * utterance HMMs of hmm::train score under main()'s acoustic_model OBJECT (src/utterance.cpp:20, src/main.cpp:45), and
+ * hmm::train writes into that object only every second iteration (acm / temp_acm swap, src/hmm.cpp:344-346) -- iterations
+ * 2k+1 and 2k+2 align under identical emission scores, so a caller that kept the compact emission buffer of the last
+ * srx_gmm_score_align_dev call may skip the call while this counter (and its feature buffer) has not changed. */
+uint64_t srx_model_version(const srx_model *m);
 
 typedef enum {
     SRX_SCORE_MFMA = 0,       /* f32-input MFMA contraction over [x^2, x, 1] (exact f32 products) */

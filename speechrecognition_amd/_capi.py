@@ -83,6 +83,7 @@ SIGNATURES = {
     "srx_model_set": (C.c_int, [vp, vp, vp, vp]),
     "srx_model_get": (C.c_int, [vp, vp, vp, vp]),
     "srx_model_copy": (C.c_int, [vp, vp]),
+    "srx_model_version": (C.c_uint64, [vp]),
     "srx_gmm_score_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp, i64, i64]),
     "srx_gmm_score": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp]),
     "srx_hmm_build_training": (C.c_int, [vp, C.c_int, vp, vp, vp]),

@@ -86,6 +86,8 @@ extern "C" int srx_model_get(srx_model *m, double *mean, double *var, float *wei
     return SRX_OK;
 }
 
+extern "C" uint64_t srx_model_version(const srx_model *m) { return m ? m->version : 0; }
+
 extern "C" int srx_model_copy(srx_model *dst, const srx_model *src) {
     SRX_REQUIRE(nullptr, dst && src, "srx_model_copy: null model");
     srx_ctx *ctx = dst->ctx;

@@ -278,6 +278,10 @@ class AcousticModel:
     def copy_from(self, other):
         check(self.ctx.lib.srx_model_copy(self.h, other.h), self.ctx.h)
 
+    def version(self):
+        """srx_model_version: advances whenever the parameters are rewritten."""
+        return int(self.ctx.lib.srx_model_version(self.h))
+
     def score(self, feats, mix_mode=SRX_MIX_COMPONENT0, path=SRX_SCORE_MFMA):
         """acoustic_model::operator() for every frame x tied state, host arrays -> [T, G]."""
         feats = np.ascontiguousarray(feats, np.float32)

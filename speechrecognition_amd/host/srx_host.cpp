@@ -1093,17 +1093,27 @@ void hmm::train(vector<utterance> &ut, int iterations) {
     Dev<int32_t> d_path((size_t)T), d_status((size_t)b.c.n_utt), d_gid((size_t)T);
     Dev<double> d_s1((size_t)G * M * (1 + FV_LEN)), d_s2((size_t)G * M * FV_LEN);
     vector<float> prevp(ut.size(), 0.0f);
+    uint64_t scored_version = 0;   // version of the utterances' model that d_e was scored under (0: never)
     for (int it = 1; it <= iterations; it++) {
         if (srx::verbose()) std::cout << "----------------------Iteration " << it << "-------------------------" << std::endl;
         // Viterbi paths for each utterance (src/hmm.cpp:257-267), emissions state-major [G][T]
+        // The utterances' model object is rewritten only every second iteration (it is acm in one and temp_acm in the next,
+        // src/hmm.cpp:344-346): while its parameters have not changed (srx_model_version) the emission scores in d_e are the
+        // ones a new pass would produce, so iterations 2k+1 and 2k+2 share one scoring pass; the alignment still moves, because
+        // the transition probabilities do (src/hmm.cpp:269-271).
         if (T == 0) {
             // an empty shard: nothing to align, the statistics below contribute zeros to the exchanges
-        } else if (compact) {
-            check(srx_gmm_score_align_dev(ctx, vit_model->device(), g_mix_mode, g_score_path, d_x.p, ld, &b.c, plan.p, d_e.p));
-            check(srx_viterbi_align_dev(ctx, &b.c, plan.p, d_e.p, 1e10f, d_path.p, d_final.p, d_status.p));
         } else {
-            check(srx_gmm_score_dev(ctx, vit_model->device(), g_mix_mode, g_score_path, d_x.p, ld, T, d_e.p, 1, T));
-            check(srx_viterbi_batch_dev(ctx, &b.c, d_e.p, 1, T, 1e10f, d_path.p, d_final.p, d_status.p));
+            srx_model *vm = vit_model->device();
+            const bool rescore = srx_model_version(vm) != scored_version;
+            if (compact) {
+                if (rescore) check(srx_gmm_score_align_dev(ctx, vm, g_mix_mode, g_score_path, d_x.p, ld, &b.c, plan.p, d_e.p));
+                check(srx_viterbi_align_dev(ctx, &b.c, plan.p, d_e.p, 1e10f, d_path.p, d_final.p, d_status.p));
+            } else {
+                if (rescore) check(srx_gmm_score_dev(ctx, vm, g_mix_mode, g_score_path, d_x.p, ld, T, d_e.p, 1, T));
+                check(srx_viterbi_batch_dev(ctx, &b.c, d_e.p, 1, T, 1e10f, d_path.p, d_final.p, d_status.p));
+            }
+            scored_version = srx_model_version(vm);
         }
         if (srx::verbose()) {
             vector<float> fin = d_final.get();

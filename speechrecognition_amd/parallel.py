@@ -97,6 +97,9 @@ class TrainingShard:
         # the context's stream as a torch stream: collectives are enqueued relative to it (see _collective)
         self.tstream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
         self.time_collectives = False
+        self.reuse_scores = True      # skip the scoring pass while the Viterbi model has not been rewritten (see iteration)
+        self._scored_key = None
+        self.scoring_passes = 0
         self.collective_events = []
         self.shift = host.DevArray.wrap(ctx, self.t_shift.data_ptr(), (G * M,), np.float32, self.t_shift)
         self.stats1 = host.DevArray.wrap(ctx, self.t_stats1.data_ptr(), (G * M * (1 + D),), np.float64, self.t_stats1)
@@ -141,12 +144,21 @@ class TrainingShard:
         ctx, hb, lib = self.ctx, self.hb, self.ctx.lib
         T = self.T
         if T > 0:
+            # The utterance HMMs score under ONE model object (src/utterance.cpp:20) that hmm::train rewrites only every second
+            # iteration (src/hmm.cpp:344-346): while its parameters have not changed, the emission scores this shard holds are
+            # the ones a new scoring pass would produce, and only the transition probabilities make the alignment move.
+            key = (int(vit_model.h.value), vit_model.version(), self.mix_mode, self.score_path)
+            rescore = not (self.reuse_scores and key == self._scored_key)
             if self.emissions == "compact":
-                hb.score_align(vit_model, self.feats_d, self.ld, self.emis, self.mix_mode, self.score_path)
+                if rescore:
+                    hb.score_align(vit_model, self.feats_d, self.ld, self.emis, self.mix_mode, self.score_path)
                 hb.viterbi_align(self.emis, 1e10, self.path, self.final, self.status)
             else:
-                vit_model.score_dev(self.feats_d, self.ld, T, self.emis, 1, T, self.mix_mode, self.score_path)
+                if rescore:
+                    vit_model.score_dev(self.feats_d, self.ld, T, self.emis, 1, T, self.mix_mode, self.score_path)
                 hb.viterbi(self.emis, 1, T, 1e10, self.path, self.final, self.status)
+            self._scored_key = key
+            self.scoring_passes += int(rescore)
             hb.train_transition_probabilities(self.path, self.status)
             check(lib.srx_em_gather_gid_dev(ctx.h, hb.c_ref(), self.path.ptr, self.status.ptr, T, self.gid.ptr), ctx.h)
         check(lib.srx_em_shift_dev(ctx.h, A.h, self.feats_d.ptr, self.ld, self.gid.ptr, T, self.logp.ptr, self.shift.ptr), ctx.h)

@@ -118,3 +118,56 @@ def test_state_model_augment_against_oracle(ctx, oracle):
     ref = np.where(rcnt > 0, rps / np.maximum(rcnt, 1).astype(np.float32), np.float32(0.5))
     np.testing.assert_allclose(pooled, ref, rtol=2e-5)
     assert pooled[C_ - 1] == 0.5
+
+
+@pytest.mark.parametrize("emissions", ["compact", "dense"])
+def test_score_reuse_across_the_model_swap_changes_nothing(ctx, emissions):
+    """hmm::train's utterance HMMs score under main()'s acoustic_model object (src/utterance.cpp:20), which the acm / temp_acm
+    swap (src/hmm.cpp:344-346) rewrites only every second iteration: the training shard skips the scoring pass while that
+    object's version has not moved.  Four iterations with the reuse on and off: two scoring passes against four, the same
+    alignments bit for bit; the models agree to the last bits that the statistics' LDS atomics leave undetermined."""
+    from speechrecognition_amd import parallel
+    rng = np.random.default_rng(41)
+    G, M, D, n_utt = 40, 2, 13, 6
+    phones = [synth.phone_string(rng, n_words=3) for _ in range(n_utt)]
+    lens = rng.integers(120, 300, n_utt)
+    fo = np.zeros(n_utt + 1, np.int64)
+    fo[1:] = np.cumsum(lens)
+    mean, var, w = synth.random_model(G, M, D, 9)
+    var *= 2.0
+    feats = np.zeros((int(fo[-1]), 39), np.float32)
+    for u in range(n_utt):
+        seg = np.sort(rng.integers(0, len(phones[u]), lens[u]))
+        feats[fo[u]:fo[u + 1], :D] = (mean[phones[u][seg], 0] + rng.standard_normal((lens[u], D)) * 1.2).astype(np.float32)
+    results = []
+    for reuse in (True, False):
+        hm = [host.build_training_hmm(p) for p in phones]
+        hb = host.HmmBatch(ctx, fo, [h[0] for h in hm], [h[1] for h in hm], [p.astype(np.int32) for p in phones])
+        X, Y = host.AcousticModel(ctx, G, M, D), host.AcousticModel(ctx, G, M, D)
+        X.set(mean, var, w)
+        Y.copy_from(X)
+        shard = parallel.TrainingShard(ctx, hb, ctx.array(feats), 39, G, M, D, None, 1, 2 if emissions == "compact" else 0,
+                                       emissions=emissions)
+        shard.reuse_scores = reuse
+        paths = []
+        for k in range(4):
+            A, B = (X, Y) if k % 2 == 0 else (Y, X)
+            v0 = X.version()
+            shard.iteration(X, A, B, 0.2)
+            ctx.sync()
+            assert (X.version() != v0) == (k % 2 == 1)      # X is rebuilt in the iterations where it is temp_acm
+            paths.append(shard.path.get()[:hb.total_frames].copy())
+        assert shard.scoring_passes == (2 if reuse else 4)
+        results.append((paths, X.get(), Y.get(), hb.trlogp()))
+        hb.close()
+        X.close()
+        Y.close()
+    (p1, x1, y1, t1), (p2, x2, y2, t2) = results
+    for a, b in zip(p1, p2):
+        assert np.array_equal(a, b)
+    assert t1.tobytes() == t2.tobytes()
+    for m1, m2 in ((x1, x2), (y1, y2)):
+        for a, b in zip(m1, m2):
+            ok = ~np.isnan(a)
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            np.testing.assert_allclose(b[ok], a[ok], rtol=1e-10)
