@@ -83,6 +83,7 @@ def main():
     ctx.profile_enable(False)
     shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, mix_mode=SRX_MIX_LOGSUMEXP, score_path=SRX_SCORE_MFMA_F16X3,
                                    emissions="compact")
+    shard.reuse_scores = False   # one model object, never rewritten here: time the iteration WITH its scoring pass
     shard.iteration(A, A, B, 0.2)   # first launches load their code objects: keep that out of the event pairs
     ctx.sync()
     ctx.profile_enable(True)
