@@ -244,6 +244,20 @@ typedef struct {
 int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
                           int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
 
+/* srx_viterbi_batch_dev without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same arguments, same kernel, same results bit for bit; the back-pointer words (srx_viterbi_batch_dev keeps them in the
+ * context's grow-only workspace) live in a fixed array inside the library instead, SRX_VITERBI_NOALLOC_MAX_WORDS 32-bit
+ * words (32 MiB) on every GPU the library runs on, held until the process ends.  The call performs no hipMalloc / hipFree
+ * and creates no events (it is not recorded by srx_profile_*).  A batch needs
+ *   (total_frames / 16 + n_utt + 1) * 64 * spl words,  spl = 1, 2, 4 for max_states <= 64, 128, 256;
+ * a larger batch is refused with SRX_ERR_INVALID (use srx_viterbi_batch_dev, or split the batch).  All calls on one GPU
+ * share that GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race -- serialise them. */
+enum { SRX_VITERBI_NOALLOC_MAX_WORDS = 8 * 1024 * 1024 };
+int srx_viterbi_batch_noalloc_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
+                                  int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev,
+                                  int32_t *status_dev);
+
 /* Alignment-mode emission scoring: every utterance's frames against that utterance's own states only -- what the
  * reference computes lazily inside hmm::viterbi (src/hmm.cpp:166, (*acm)(*fvs[i], target->ctx) for the targets of the
  * active states) -- instead of the dense [T][G] matrix of srx_gmm_score_dev.  The plan (host frame/state offsets of the

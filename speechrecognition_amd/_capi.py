@@ -88,6 +88,7 @@ SIGNATURES = {
     "srx_gmm_score": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp]),
     "srx_hmm_build_training": (C.c_int, [vp, C.c_int, vp, vp, vp]),
     "srx_viterbi_batch_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, i64, i64, C.c_float, vp, vp, vp]),
+    "srx_viterbi_batch_noalloc_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, i64, i64, C.c_float, vp, vp, vp]),
     "srx_align_plan_create": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(vp)]),
     "srx_align_plan_destroy": (None, [vp]),
     "srx_align_plan_emission_count": (C.c_int64, [vp]),

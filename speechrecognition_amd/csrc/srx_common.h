@@ -55,6 +55,10 @@ struct SrxProf {
 // Returns a device workspace of at least `bytes` (contents undefined).  Grow-only, owned by ctx.
 int srx_workspace(srx_ctx *ctx, int slot, size_t bytes, void **out);
 
+// srx_viterbi.hip: looks up this device's copy of the fixed back-pointer array of srx_viterbi_batch_noalloc_dev
+// (the device must be current).  Called by srx_ctx_create.
+void srx_viterbi_noalloc_setup(int device);
+
 extern char g_srx_create_err[512];
 
 static inline int srx_fail(srx_ctx *ctx, int code, const char *fmt, ...) {

@@ -35,6 +35,7 @@ extern "C" int srx_ctx_create(int device, void *stream, srx_ctx **out) {
         }
         c->own_stream = true;
     }
+    srx_viterbi_noalloc_setup(device);   // per-device address of the fixed back-pointer scratch (srx_viterbi.hip)
     *out = c;
     return SRX_OK;
 }

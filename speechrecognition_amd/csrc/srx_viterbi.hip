@@ -20,6 +20,7 @@
 // 2-bit back-pointers packed 16 frames to a word, device-side backtrace with the current state in
 // an SGPR.
 #include <cstdlib>
+#include <mutex>
 
 #include "srx_common.h"
 
@@ -553,12 +554,20 @@ __global__ __launch_bounds__(256) void k_train_transitions(int n_utt, const int6
     }
 }
 
+static int64_t vit_occ_min() {
+    static const int64_t v = std::getenv("SRX_VIT_OCC_MIN_UTT") ? std::atoll(std::getenv("SRX_VIT_OCC_MIN_UTT")) : 8192;
+    return v;
+}
+
 static size_t viterbi_words(const srx_hmm_batch *hmm, int spl) {
     return ((size_t)(hmm->total_frames >> 4) + (size_t)hmm->n_utt + 1) * 64 * spl;
 }
 
+// `bp_words` != nullptr: the caller brings the back-pointer words (at least `bp_capacity` of them) and the call allocates
+// nothing -- no workspace growth and no profiling events (srx_viterbi_batch_noalloc_dev below).
 static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t, int64_t stride_g,
-                          const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
+                          const int64_t *ebase_dev, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev,
+                          uint32_t *bp_words = nullptr, size_t bp_capacity = 0) {
     SRX_REQUIRE(ctx, hmm && hmm->n_utt >= 0, "srx_viterbi_batch_dev: null or negative batch");
     if (hmm->n_utt == 0) return SRX_OK;   // an empty corpus: the reference's `for i < ut.size()` does nothing (src/hmm.cpp:258)
     SRX_REQUIRE(ctx, emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
@@ -570,14 +579,20 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     SRX_REQUIRE(ctx, total_frames >= 0, "srx_viterbi_batch_dev: negative total_frames");
     const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : 4);
     const size_t words = viterbi_words(hmm, spl);
-    void *ws = nullptr;
-    int rc = srx_workspace(ctx, 1, words * sizeof(uint32_t), &ws);
-    if (rc != SRX_OK) return rc;
+    void *ws = bp_words;
+    if (bp_words) {
+        SRX_REQUIRE(ctx, words <= bp_capacity,
+                    "srx_viterbi_batch_noalloc_dev: the batch needs %zu back-pointer words (total_frames / 16 + n_utt + 1 rows of %d), "
+                    "the fixed scratch holds %zu; use srx_viterbi_batch_dev", words, 64 * spl, bp_capacity);
+    } else {
+        int rc = srx_workspace(ctx, 1, words * sizeof(uint32_t), &ws);
+        if (rc != SRX_OK) return rc;
+    }
     const bool beam = beam_width < 1e10f;
     dim3 grid(hmm->n_utt), block(64);
     // several times more utterances than the latency build could keep resident (two waves per SIMD): the throughput build
     // (VitCfg).  Measured cross-over: equal at 3,000-6,000 utterances, -6 % at 10,000, -30 % at 100,000.
-    static const int64_t occ_min = std::getenv("SRX_VIT_OCC_MIN_UTT") ? std::atoll(std::getenv("SRX_VIT_OCC_MIN_UTT")) : 8192;
+    const int64_t occ_min = vit_occ_min();
     const bool many = hmm->n_utt >= occ_min;
     const bool vec = !ebase_dev && stride_t == 1 && stride_g % 4 == 0 && stride_g >= total_frames &&
                      (reinterpret_cast<uintptr_t>(emis_dev) & 15) == 0;
@@ -594,7 +609,9 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
         else if (spl == 2) { if (beam) SRX_VIT(2, true); else SRX_VIT(2, false); }
         else { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
     };
-    {
+    if (bp_words) {
+        launch();   // no event pair: creating one allocates
+    } else {
         SrxProf prof_(ctx, "k_viterbi");
         launch();
     }
@@ -609,6 +626,46 @@ extern "C" int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, con
                                      int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev) {
     SRX_ENTER(ctx, "srx_viterbi_batch_dev");
     return viterbi_launch(ctx, hmm, emis_dev, stride_t, stride_g, nullptr, beam_width, path_dev, final_logp_dev, status_dev);
+}
+
+// ------------------------------------------------------------------------------------------
+// srx_viterbi_batch_noalloc_dev: srx_viterbi_batch_dev for callers that cannot allocate (HIP graph capture, serving
+// loops, harnesses that forbid hipMalloc).  The back-pointer words live in a fixed array of this code object instead of
+// the context's grow-only workspace.  Every GPU the library runs on holds its own copy of the array, at its own address,
+// until the process ends; `scratch` below is only the host-side handle of that symbol, never an address a kernel can
+// use: the per-device address comes from hipGetSymbolAddress (srx_viterbi_noalloc_setup, called by srx_ctx_create with
+// the context's device current) and that pointer is what the kernel is given.  The kernel writes every word it later
+// reads, so nothing has to be cleared between calls; calls that overlap on one GPU share the array and race.
+// ------------------------------------------------------------------------------------------
+static constexpr size_t SRX_VIT_SCRATCH_WORDS = (size_t)SRX_VITERBI_NOALLOC_MAX_WORDS;
+static __device__ __align__(256) uint32_t scratch[SRX_VIT_SCRATCH_WORDS];
+static uint32_t *g_scratch_ptr[SRX_MAX_DEVICES] = {nullptr};
+static hipError_t g_scratch_err[SRX_MAX_DEVICES] = {hipSuccess};
+static std::mutex g_scratch_mu;
+
+// Once per device, with that device current (srx_ctx_create).  A failure is kept and reported by the entry point; the
+// rest of the library does not depend on the array.
+void srx_viterbi_noalloc_setup(int device) {
+    if (device < 0 || device >= SRX_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return;
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    g_scratch_err[device] = e;
+    if (e == hipSuccess) g_scratch_ptr[device] = reinterpret_cast<uint32_t *>(p);
+    (void)vit_occ_min();   // reads the environment once, here, not inside the entry point
+}
+
+extern "C" int srx_viterbi_batch_noalloc_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
+                                             int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev,
+                                             int32_t *status_dev) {
+    SRX_ENTER(ctx, "srx_viterbi_batch_noalloc_dev");
+    uint32_t *ptr = g_scratch_ptr[ctx->device];
+    if (!ptr)
+        return srx_fail(ctx, SRX_ERR_DEVICE, "srx_viterbi_batch_noalloc_dev: the scratch array has no address on device %d (%s)",
+                        ctx->device, hipGetErrorString(g_scratch_err[ctx->device]));
+    return viterbi_launch(ctx, hmm, emis_dev, stride_t, stride_g, nullptr, beam_width, path_dev, final_logp_dev, status_dev, ptr,
+                          SRX_VIT_SCRATCH_WORDS);
 }
 
 int srx_align_plan_n_utt(const srx_align_plan *plan);   // srx_gmm_f16_align.hip

@@ -335,15 +335,17 @@ class HmmBatch:
     def c_ref(self):
         return C.byref(self.c)
 
-    def viterbi(self, emis_d, stride_t, stride_g=1, beam=1e10, path_d=None, final_d=None, status_d=None):
+    def viterbi(self, emis_d, stride_t, stride_g=1, beam=1e10, path_d=None, final_d=None, status_d=None, noalloc=False):
         """hmm::viterbi for every utterance (src/hmm.cpp:150-224); emission (t, col) at
-        emis[t*stride_t + col*stride_g] (frame-major [T, G]: (G, 1); state-major [G, T]: (1, T))."""
+        emis[t*stride_t + col*stride_g] (frame-major [T, G]: (G, 1); state-major [G, T]: (1, T)).
+        noalloc: srx_viterbi_batch_noalloc_dev (back-pointers in the library's fixed per-GPU array; the caller should
+        then pass the three output buffers too, or this wrapper allocates them)."""
         ctx = self.ctx
         path_d = path_d or ctx.zeros((max(self.total_frames, 1),), np.int32)
         final_d = final_d or ctx.zeros((max(self.n_utt, 1),), np.float32)
         status_d = status_d or ctx.zeros((max(self.n_utt, 1),), np.int32)
-        check(ctx.lib.srx_viterbi_batch_dev(ctx.h, C.byref(self.c), emis_d.ptr, stride_t, stride_g, beam, path_d.ptr,
-                                            final_d.ptr, status_d.ptr), ctx.h)
+        fn = ctx.lib.srx_viterbi_batch_noalloc_dev if noalloc else ctx.lib.srx_viterbi_batch_dev
+        check(fn(ctx.h, C.byref(self.c), emis_d.ptr, stride_t, stride_g, beam, path_d.ptr, final_d.ptr, status_d.ptr), ctx.h)
         return path_d, final_d, status_d
 
     def train_transition_probabilities(self, path_d, status_d):
