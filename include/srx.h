@@ -139,6 +139,48 @@ int srx_partial_dft_batch_dev(srx_ctx *ctx, const srx_mfcc_plan *plan, const flo
 int srx_partial_dft_batch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples, const int64_t *sample_off, int n_utt,
                           float *spec, int64_t *frame_off);
 
+/* ---------------------------------------------------------------- the MFCC stages one by one --------
+ * Inside srx_mfcc_batch* the stages below are fused and their intermediates never leave the chip.  The reference also has
+ * each as a function of its own; these entry points are those functions, evaluated in the reference's operation order
+ * (f64 product and add with the running sum rounded to f32 per add; sequential f32 accumulation of filter taps) with the
+ * cosines from host-built f64 tables, so the results equal the CPU restatement bit for bit (log(x+1): to the last place
+ * of the device's logf).  One thread per output: correctness-first forms for callers that work a frame at a time; the
+ * batch entry points are the fast path.  `_dev` forms take device pointers and row strides in elements. */
+
+/* Clip::partial_dft(out, len, stack) / Clip::dft  src/clip.cpp:166-194 for n_frames windows of N samples each:
+ * y[n] = x[n] * window[n] for n < N/2 (Clip::operator[] const, src/clip.cpp:123-125; window == NULL: rectangular_window),
+ * re/im accumulated over n < N/2 only (src/clip.cpp:181), out[k] = sqrt(re^2 + im^2) / sqrt(N) for k < len, the mirrored
+ * write out[N-k-1] when len > N/2 (src/clip.cpp:186-192: later writes win), added to what out holds when `stack`.
+ * len <= N.  Host form: frames[n_frames][N], out[n_frames][len]; device form: rows of at least N/2 samples (only the first
+ * half of a window is read). */
+int srx_partial_dft_frames_dev(srx_ctx *ctx, const float *frames_dev, int64_t ld, const float *window_dev, int N, int len,
+                               int64_t n_frames, int stack, float *out_dev, int64_t ldo);
+int srx_partial_dft_frames(srx_ctx *ctx, const float *frames, const float *window /*[N/2] or NULL*/, int N, int len,
+                           int64_t n_frames, int stack, float *out);
+
+/* filterbank::operator()(spectrum) = filter::operator() of every filter  src/mfcc.cpp:143-149, 161-167:
+ * out[r][i] = sum over b = (int)(c_i - w_i) .. (int)(c_i + w_i) of filter::get(b) * spec[r][b], f32 in that order.
+ * `fb` is a HOST array (n_filters <= 64).  A filter that reaches outside [0, n_bins) is refused (the reference reads
+ * whatever lies beside its array). */
+int srx_filterbank_apply_dev(srx_ctx *ctx, const srx_filter *fb, int n_filters, const float *spec_dev, int64_t ld, int n_bins,
+                             int64_t n_rows, float *out_dev, int64_t ldo);
+int srx_filterbank_apply(srx_ctx *ctx, const srx_filter *fb, int n_filters, const float *spec, int n_bins, int64_t n_rows,
+                         float *out);
+
+/* log(T *buf, int len)  src/utils.hpp:55-60 for T = float: buf[i] = logf(buf[i] + 1), in place. */
+int srx_log1p_dev(srx_ctx *ctx, float *buf_dev, int64_t n);
+int srx_log1p(srx_ctx *ctx, float *buf, int64_t n);
+
+/* dct(filtered, len, nparams)  src/mfcc.cpp:205-214 for n_rows vectors: out[r][j] = sum_i in[r][i] * cos(j*i*pi/len),
+ * j < nparams, the product and the add in f64, the running sum rounded to f32 after every add. */
+int srx_dct_dev(srx_ctx *ctx, const float *in_dev, int64_t ld, int len, int nparams, int64_t n_rows, float *out_dev, int64_t ldo);
+int srx_dct(srx_ctx *ctx, const float *in, int len, int nparams, int64_t n_rows, float *out);
+
+/* featurevec::compute_deltas / compute_delta2s for ONE vector  src/mfcc.cpp:73-92: out[q] = (hi[q] - lo[q]) / (float)span,
+ * hi / lo = the coefficients (or deltas) of the neighbours k and j, span = k - j (0, 1 or 2).  Host pointers.  The batch
+ * form -- compute_deltas(vector) of src/mfcc.cpp:95-102 -- is srx_features_batch* with WL = -1. */
+int srx_delta(srx_ctx *ctx, const float *hi, const float *lo, int span, float *out, int64_t n);
+
 /* Clip::rmsAmplitude + Clip::normalizeVolume  src/clip.cpp:151-164 (in place, per utterance) */
 int srx_normalize_volume_dev(srx_ctx *ctx, float *samples_dev, const int64_t *sample_off_dev, int n_utt,
                              float target_rms, float *scratch_scale_dev);
@@ -152,7 +194,8 @@ int srx_preemphasis_dev(srx_ctx *ctx, float *samples_dev, float *scratch_dev, co
                         int n_utt, int64_t total_samples, float alpha);
 
 /* read_features smoothing + compute_deltas  src/mfcc.cpp:296-312, 73-102:
- * ceps [total_frames][n_ceps] -> feats [total_frames][3*n_ceps] = [coeffs|deltas|delta2s]. */
+ * ceps [total_frames][n_ceps] -> feats [total_frames][3*n_ceps] = [coeffs|deltas|delta2s].
+ * WL = -1: no smoothing stage at all -- compute_deltas(vector) alone (src/mfcc.cpp:95-102), coefficients copied through. */
 int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const float *ceps_dev, const int64_t *frame_off_dev,
                            int n_utt, int64_t total_frames, float *feats_dev);
 int srx_features_batch(srx_ctx *ctx, int WL, int n_ceps, const float *ceps, const int64_t *frame_off, int n_utt,
@@ -191,6 +234,12 @@ int srx_model_copy(srx_model *dst, const srx_model *src); /* acoustic_model(acou
  * 2k+1 and 2k+2 align under identical emission scores, so a caller that kept the compact emission buffer of the last
  * srx_gmm_score_align_dev call may skip the call while this counter (and its feature buffer) has not changed. */
 uint64_t srx_model_version(const srx_model *m);
+
+/* gaussian::operator()(fv) / gaussian::logprob  src/gmm.cpp:41-54 for ONE Gaussian that is not part of a model, over T
+ * feature vectors (host pointers; mean/var [D] doubles for the reference's long double): out[t] in the reference's
+ * operation order (the arithmetic of SRX_SCORE_EXACT below).  gaussian::prob is exp() of it (src/gmm.cpp:57-59). */
+int srx_gaussian_logprob(srx_ctx *ctx, const float *feats, int ld, int64_t T, int D, const double *mean, const double *var,
+                         float logwt, float *out);
 
 typedef enum {
     SRX_SCORE_MFMA = 0,       /* f32-input MFMA contraction over [x^2, x, 1] (exact f32 products) */

@@ -47,6 +47,11 @@ def lib():
         L.orc_num_frames.restype = C.c_long
         L.orc_num_frames.argtypes = [C.c_long, C.c_int, C.c_int]
         L.orc_partial_dft.argtypes = [f32p, C.c_int, C.c_int, f32p]
+        L.orc_partial_dft_win.argtypes = [f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, f32p]
+        L.orc_log1p.argtypes = [f32p, C.c_long]
+        L.orc_compute_deltas.argtypes = [f32p, C.c_long, C.c_int]
+        L.orc_filterbank_apply.argtypes = [C.c_void_p, C.c_int, f32p, f32p]
+        L.orc_dct.argtypes = [f32p, C.c_int, C.c_int, f32p]
         L.orc_mfcc_frame.argtypes = [f32p, C.c_int, C.c_void_p, C.c_int, C.c_int, f32p, C.c_void_p]
         L.orc_write_features.restype = C.c_long
         L.orc_write_features.argtypes = [f32p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, f32p]
@@ -107,6 +112,57 @@ def partial_dft(frame, N, nbins):
     out = np.zeros(max(nbins, N), np.float32)
     lib().orc_partial_dft(frame, N, nbins, out)
     return out[:nbins]
+
+
+def partial_dft_win(frame, win, N, nbins, stack=False, out=None):
+    """Clip::partial_dft(out, nbins, stack) with window values win[N/2] (None: rectangular)."""
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    out = np.zeros(nbins, np.float32) if out is None else np.ascontiguousarray(out, np.float32).copy()
+    w = None if win is None else np.ascontiguousarray(win, np.float32)
+    lib().orc_partial_dft_win(frame, None if w is None else w.ctypes.data, N, nbins, 1 if stack else 0, out)
+    return out
+
+
+def hamming(n, N):
+    return np.float32(lib().orc_hamming(n, N))
+
+
+def filterbank_apply(fb, spec):
+    spec = np.ascontiguousarray(spec, dtype=np.float32)
+    out = np.zeros(len(fb), np.float32)
+    lib().orc_filterbank_apply(fb.ctypes.data, len(fb), spec, out)
+    return out
+
+
+def log1p(buf):
+    buf = np.ascontiguousarray(buf, dtype=np.float32).copy()
+    lib().orc_log1p(buf.reshape(-1), buf.size)
+    return buf
+
+
+def dct(filtered, nparams):
+    filtered = np.ascontiguousarray(filtered, dtype=np.float32)
+    out = np.zeros(nparams, np.float32)
+    lib().orc_dct(filtered, len(filtered), nparams, out)
+    return out
+
+
+def compute_deltas(coeffs):
+    """compute_deltas(vector) on coefficients [n, nparams] -> [n, 3*nparams]."""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.float32)
+    n, npar = coeffs.shape
+    feats = np.zeros((n, 3 * npar), np.float32)
+    feats[:, :npar] = coeffs
+    lib().orc_compute_deltas(feats, n, npar)
+    return feats
+
+
+def gaussian_logprob(fv, mean, var, logwt):
+    """gaussian::operator() of one Gaussian on one feature vector."""
+    fv = np.ascontiguousarray(fv, dtype=np.float32)
+    mean = np.ascontiguousarray(mean, dtype=np.longdouble)
+    var = np.ascontiguousarray(var, dtype=np.longdouble)
+    return np.float32(lib().orc_gaussian_logprob(fv, mean, var, np.float32(logwt), len(mean)))
 
 
 def write_features(x, wl=320, hop=160, fb=None, nparams=13, alpha=0.96):

@@ -145,6 +145,54 @@ void orc_partial_dft(const float *x, int N, int len, float *out) {
     }
 }
 
+/* Clip::partial_dft with its `stack` argument and an arbitrary window  src/clip.cpp:174-194, statement by statement:
+ * win[n] = window(n, N) for n < N/2 (NULL: rectangular_window, src/utils.cpp:13-15); out has len entries and is read when
+ * stack != 0.  Requires len <= N (beyond that the reference writes out[N-k-1] at a negative index). */
+void orc_partial_dft_win(const float *x, const float *win, int N, int len, int stack, float *out) {
+    float rootn_inv = (float)(1.0f / sqrt((double)N));
+    int mirror = len > N / 2;
+    for (int k = 0; k < len; k++) {
+        float re = 0, im = 0;
+        for (int n = 0; n < N / 2; n++) {
+            float y = x[n] * (win ? win[n] : 1.0f);
+            re = (float)((double)re + (double)y * cos(-2 * M_PI * k * n / N));
+            im = (float)((double)im + (double)y * sin(-2 * M_PI * k * n / N));
+        }
+        float res = sqrtf(re * re + im * im) * rootn_inv;
+        if (stack) {
+            out[k] += res;
+            if (mirror && N - k - 1 < len) out[N - k - 1] += res;
+        } else {
+            out[k] = res;
+            if (mirror && N - k - 1 < len) out[N - k - 1] = res;
+        }
+    }
+}
+
+/* log(T *buf, int len)  src/utils.hpp:55-60 with T = float */
+void orc_log1p(float *buf, long n) {
+    for (long i = 0; i < n; i++) buf[i] = logf(buf[i] + 1);
+}
+
+/* compute_deltas(vector<featurevec*>)  src/mfcc.cpp:95-102 with featurevec::compute_deltas / compute_delta2s  :73-92:
+ * feats n x 3*nparams, coefficients in [0, nparams) on entry; fills the deltas and delta-deltas. */
+void orc_compute_deltas(float *feats, long n, int nparams) {
+    int ld = 3 * nparams;
+    for (long i = 0; i < n; i++) {
+        long j = i - 1, k = i + 1;
+        if (j < 0) j = 0;
+        if (k == n) k--;
+        for (int q = 0; q < nparams; q++) feats[i * ld + nparams + q] = (feats[k * ld + q] - feats[j * ld + q]) / (float)(k - j);
+    }
+    for (long i = 0; i < n; i++) {
+        long j = i - 1, k = i + 1;
+        if (j < 0) j = 0;
+        if (k == n) k--;
+        for (int q = 0; q < nparams; q++)
+            feats[i * ld + 2 * nparams + q] = (feats[k * ld + nparams + q] - feats[j * ld + nparams + q]) / (float)(k - j);
+    }
+}
+
 /* filterbank::operator() + filter::operator()  src/mfcc.cpp:143-149,161-167 */
 void orc_filterbank_apply(const orc_filter *fb, int nfilt, const float *spec, float *out) {
     for (int f = 0; f < nfilt; f++) {

@@ -70,6 +70,16 @@ SIGNATURES = {
     "srx_mfcc_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp]),
     "srx_partial_dft_batch_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp]),
     "srx_partial_dft_batch": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp]),
+    "srx_partial_dft_frames_dev": (C.c_int, [vp, vp, i64, vp, C.c_int, C.c_int, i64, C.c_int, vp, i64]),
+    "srx_partial_dft_frames": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, i64, C.c_int, vp]),
+    "srx_filterbank_apply_dev": (C.c_int, [vp, C.POINTER(srx_filter), C.c_int, vp, i64, C.c_int, i64, vp, i64]),
+    "srx_filterbank_apply": (C.c_int, [vp, C.POINTER(srx_filter), C.c_int, vp, C.c_int, i64, vp]),
+    "srx_log1p_dev": (C.c_int, [vp, vp, i64]),
+    "srx_log1p": (C.c_int, [vp, vp, i64]),
+    "srx_dct_dev": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, i64, vp, i64]),
+    "srx_dct": (C.c_int, [vp, vp, C.c_int, C.c_int, i64, vp]),
+    "srx_delta": (C.c_int, [vp, vp, vp, C.c_int, vp, i64]),
+    "srx_gaussian_logprob": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, vp, vp, C.c_float, vp]),
     "srx_normalize_volume_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_float, vp]),
     "srx_scale_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "srx_rms_amplitude_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),

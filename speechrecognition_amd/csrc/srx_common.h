@@ -34,6 +34,13 @@ struct srx_ctx {
     };
     bool prof_on = false;
     std::vector<prof_rec> prof;
+    // small constant tables of the per-frame operators (srx_frameops.hip): f64 twiddles keyed by (window, bins), f64 DCT
+    // cosines keyed by (len, nparams).  Built on first use, freed with the context.
+    struct table_rec {
+        int kind, a, b;
+        void *dev;
+    };
+    std::vector<table_rec> tables;
 };
 
 // Brackets one kernel launch with events on the context's stream while profiling is enabled.

@@ -48,6 +48,7 @@ extern "C" void srx_ctx_destroy(srx_ctx *ctx) {
     for (int i = 0; i < 4; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto &t : ctx->tables) (void)hipFree(t.dev);
     delete ctx;
 }
 

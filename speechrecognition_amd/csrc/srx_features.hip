@@ -9,6 +9,7 @@
 
 __device__ __forceinline__ float smooth_at(const float *__restrict__ raw, int64_t base, int64_t n, int64_t i, int q,
                                            int nc, int WL) {
+    if (WL < 0) return raw[(base + i) * nc + q];   // compute_deltas alone (src/mfcc.cpp:95-102): the coefficients as they are
     float s = 0.0f;
     int NF = 0;
     for (int w = -WL; w <= WL; w++) {
@@ -106,7 +107,7 @@ extern "C" int srx_features_batch_dev(srx_ctx *ctx, int WL, int n_ceps, const fl
                                       int n_utt, int64_t total_frames, float *feats_dev) {
     SRX_ENTER(ctx, "srx_features_batch_dev");
     SRX_REQUIRE(ctx, ceps_dev && frame_off_dev && feats_dev, "srx_features_batch_dev: null argument");
-    SRX_REQUIRE(ctx, WL >= 0 && WL <= 64 && n_ceps >= 1 && n_utt >= 0 && total_frames >= 0, "srx_features_batch_dev: bad size");
+    SRX_REQUIRE(ctx, WL >= -1 && WL <= 64 && n_ceps >= 1 && n_utt >= 0 && total_frames >= 0, "srx_features_batch_dev: bad size");
     if (n_utt == 0 || total_frames == 0) return SRX_OK;
     SRX_REQUIRE(ctx, n_ceps <= 64, "srx_features_batch_dev: n_ceps %d > 64", n_ceps);
     const int64_t nblk = ceil_div64(total_frames, FBK);

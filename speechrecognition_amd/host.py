@@ -308,6 +308,65 @@ def build_training_hmm(phones):
     return ntr, tr, ctx3
 
 
+# ---- the MFCC stages and the single Gaussian as calls of their own (csrc/srx_frameops.hip: reference-order kernels) ----
+def _as_filters(fb):
+    fb = np.ascontiguousarray(fb, dtype=FILTER_DT)
+    return fb, fb.ctypes.data_as(C.POINTER(srx_filter))
+
+
+def partial_dft_frames(ctx, frames, window, len_, stack=False, out=None):
+    """Clip::partial_dft(out, len, stack) (src/clip.cpp:174-194) of every row of frames [n, N]; window: [N/2] values of
+    the clip's window function or None (rectangular)."""
+    frames = np.ascontiguousarray(frames, np.float32)
+    n, N = frames.shape
+    res = np.zeros((n, len_), np.float32) if out is None else np.ascontiguousarray(out, np.float32).copy()
+    w = None if window is None else np.ascontiguousarray(window, np.float32)
+    check(ctx.lib.srx_partial_dft_frames(ctx.h, _ptr(frames), None if w is None else _ptr(w), N, len_, n, int(stack), _ptr(res)), ctx.h)
+    return res
+
+
+def filterbank_apply(ctx, fb, spec):
+    """filterbank::operator() (src/mfcc.cpp:143-167) of every row of spec [n, n_bins] -> [n, len(fb)]."""
+    spec = np.ascontiguousarray(spec, np.float32)
+    fb, fbp = _as_filters(fb)
+    out = np.zeros((spec.shape[0], len(fb)), np.float32)
+    check(ctx.lib.srx_filterbank_apply(ctx.h, fbp, len(fb), _ptr(spec), spec.shape[1], spec.shape[0], _ptr(out)), ctx.h)
+    return out
+
+
+def log1p(ctx, buf):
+    """log(buf, len) of src/utils.hpp:55-60 (a copy is returned)."""
+    buf = np.ascontiguousarray(buf, np.float32).copy()
+    check(ctx.lib.srx_log1p(ctx.h, _ptr(buf), buf.size), ctx.h)
+    return buf
+
+
+def dct(ctx, filtered, nparams):
+    """dct (src/mfcc.cpp:205-214) of every row of filtered [n, len] -> [n, nparams]."""
+    filtered = np.ascontiguousarray(filtered, np.float32)
+    out = np.zeros((filtered.shape[0], nparams), np.float32)
+    check(ctx.lib.srx_dct(ctx.h, _ptr(filtered), filtered.shape[1], nparams, filtered.shape[0], _ptr(out)), ctx.h)
+    return out
+
+
+def delta(ctx, hi, lo, span):
+    """featurevec::compute_deltas of one vector (src/mfcc.cpp:73-92): (hi - lo) / span."""
+    hi, lo = np.ascontiguousarray(hi, np.float32), np.ascontiguousarray(lo, np.float32)
+    out = np.zeros_like(hi)
+    check(ctx.lib.srx_delta(ctx.h, _ptr(hi), _ptr(lo), int(span), _ptr(out), hi.size), ctx.h)
+    return out
+
+
+def gaussian_logprob(ctx, feats, mean, var, logwt):
+    """gaussian::operator() (src/gmm.cpp:41-49) of one free-standing Gaussian on every row of feats [T, ld >= D]."""
+    feats = np.ascontiguousarray(feats, np.float32)
+    mean, var = np.ascontiguousarray(mean, np.float64), np.ascontiguousarray(var, np.float64)
+    out = np.zeros(feats.shape[0], np.float32)
+    check(ctx.lib.srx_gaussian_logprob(ctx.h, _ptr(feats), feats.shape[1], feats.shape[0], len(mean), _ptr(mean), _ptr(var),
+                                       float(logwt), _ptr(out)), ctx.h)
+    return out
+
+
 class HmmBatch:
     """A ragged batch of per-utterance training HMMs on the device (utterance.hmm of src/utterance.hpp:30)."""
 

@@ -118,10 +118,64 @@ srx_comm *communicator() {
 int rank() { return g_rank; }
 int world() { return g_world; }
 
+// ---- id rendezvous through a file ----
+namespace {
+const char COMM_MAGIC[8] = {'S', 'R', 'X', 'C', 'O', 'M', 'M', '1'};
+const size_t COMM_FILE_BYTES = 8 + 8 + SRX_COMM_ID_BYTES;
+}  // namespace
+
+// What every rank of one launch knows and another launch does not: the launcher's rendezvous values.  FNV-1a over them.
+// A launcher that sets none of them leaves only WORLD_SIZE: set SRX_COMM_NONCE (any string, the same on every rank, new
+// for every launch) when a fixed SRX_COMM_FILE path is reused.
+uint64_t launch_nonce() {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (const char *name : {"SRX_COMM_NONCE", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE"}) {
+        const char *v = std::getenv(name);
+        for (const char *p = v ? v : ""; *p; p++) h = (h ^ (unsigned char)*p) * 0x100000001b3ull;
+        h = (h ^ 0xffu) * 0x100000001b3ull;   // field separator
+    }
+    return h;
+}
+
+void publish_comm_id(const string &file, uint64_t nonce, const unsigned char *id) {
+    std::remove(file.c_str());   // whatever an earlier launch left: gone before the new one appears (rename is atomic)
+    const string tmp = file + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) throw srx_error(SRX_ERR_IO, "cannot write " + tmp);
+    const bool ok = std::fwrite(COMM_MAGIC, 1, 8, f) == 8 && std::fwrite(&nonce, 1, 8, f) == 8 &&
+                    std::fwrite(id, 1, SRX_COMM_ID_BYTES, f) == (size_t)SRX_COMM_ID_BYTES;
+    if (std::fclose(f) != 0 || !ok) throw srx_error(SRX_ERR_IO, "cannot write " + tmp);
+    if (std::rename(tmp.c_str(), file.c_str()) != 0) throw srx_error(SRX_ERR_IO, "cannot publish " + file);
+}
+
+bool await_comm_id(const string &file, uint64_t nonce, unsigned char *id, int timeout_ms) {
+    for (int waited = 0;; waited += 10) {
+        FILE *f = std::fopen(file.c_str(), "rb");
+        if (f) {
+            unsigned char buf[COMM_FILE_BYTES + 1];
+            const size_t got = std::fread(buf, 1, sizeof buf, f);
+            std::fclose(f);
+            uint64_t theirs = 0;
+            if (got == COMM_FILE_BYTES && !std::memcmp(buf, COMM_MAGIC, 8)) {
+                std::memcpy(&theirs, buf + 8, 8);
+                if (theirs == nonce) {
+                    std::memcpy(id, buf + 16, SRX_COMM_ID_BYTES);
+                    return true;
+                }
+            }
+            // anything else -- another launch's nonce, a bare 128-byte id of an older build, a partial file -- is not ours
+        }
+        if (waited >= timeout_ms) return false;
+        struct timespec ts = {0, 10 * 1000 * 1000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 // Joins the ranks of one launch (RANK / WORLD_SIZE in the environment, as torchrun, mpirun wrappers and SLURM scripts set
-// them).  The 128-byte id of rank 0 travels through the file SRX_COMM_FILE (any path all ranks can read: rank 0 writes
-// <file>.tmp and renames it, the others wait for it).  SRX_COMM_SHM=/name selects the host rehearsal transport instead
-// (ranks sharing one GPU, see include/srx.h).
+// them).  The 128-byte id of rank 0 travels through the file SRX_COMM_FILE (any path all ranks can read) tagged with the
+// launch's nonce: rank 0 removes what is there, writes <file>.tmp and renames it; the others wait for a file that carries
+// their nonce; rank 0 removes the file again once every rank has joined.  SRX_COMM_SHM=/name selects the host rehearsal
+// transport instead (ranks sharing one GPU, see include/srx.h).
 void init_distributed() {
     const char *r = std::getenv("RANK"), *w = std::getenv("WORLD_SIZE");
     if (!r || !w || std::atoi(w) <= 1 || g_comm) return;
@@ -135,30 +189,16 @@ void init_distributed() {
         const char *file = std::getenv("SRX_COMM_FILE");
         if (!file) throw srx_error(SRX_ERR_INVALID, "WORLD_SIZE > 1 needs SRX_COMM_FILE (where rank 0 publishes the RCCL id) or SRX_COMM_SHM");
         unsigned char id[SRX_COMM_ID_BYTES];
+        const uint64_t nonce = launch_nonce();
         if (g_rank == 0) {
             rc = srx_comm_unique_id(id);
             if (rc != SRX_OK) throw srx_error(rc, srx_last_error(nullptr));
-            string tmp = string(file) + ".tmp";
-            FILE *f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) throw srx_error(SRX_ERR_IO, "cannot write " + tmp);
-            std::fclose(f);
-            if (std::rename(tmp.c_str(), file) != 0) throw srx_error(SRX_ERR_IO, string("cannot publish ") + file);
-        } else {
-            bool got = false;
-            for (int tries = 0; tries < 6000 && !got; tries++) {   // up to 60 s
-                FILE *f = std::fopen(file, "rb");
-                if (f) {
-                    got = std::fread(id, 1, sizeof id, f) == sizeof id;
-                    std::fclose(f);
-                }
-                if (!got) {
-                    struct timespec ts = {0, 10 * 1000 * 1000};
-                    nanosleep(&ts, nullptr);
-                }
-            }
-            if (!got) throw srx_error(SRX_ERR_IO, string("rank 0 never published ") + file);
+            publish_comm_id(file, nonce, id);
+        } else if (!await_comm_id(file, nonce, id, 60 * 1000)) {
+            throw srx_error(SRX_ERR_IO, string("rank 0 never published an id of this launch in ") + file);
         }
         rc = srx_comm_create(ctx, g_rank, g_world, id, &g_comm);
+        if (g_rank == 0) std::remove(file);   // collective: every rank has read it by now
     }
     if (rc != SRX_OK) throw srx_error(rc, srx_last_error(ctx));
 }
@@ -214,6 +254,9 @@ vector<string> readlines(const char *fname) {
 
 float hamming_window(int x, int len) { return 0.54f + 0.46 * std::cos(2 * M_PI * x / (len - 1)); }
 float rectangular_window(int, int) { return 1; }
+void log(float *buf, int len) {
+    if (len > 0) check(srx_log1p(srx::context(), buf, len));
+}
 
 // ============================================================================================ clip
 ClipBuffer::~ClipBuffer() {}
@@ -222,6 +265,18 @@ ClipArrayBuffer::~ClipArrayBuffer() { delete[] buf; }
 float &ClipArrayBuffer::operator[](int i) { return buf[i]; }
 int ClipArrayBuffer::length() const { return n; }
 float *ClipArrayBuffer::data() { return buf; }
+
+ClipVectorBuffer::ClipVectorBuffer() {}
+void ClipVectorBuffer::ensure(int additional) {
+    if (samples.capacity() - samples.size() < (size_t)additional) samples.reserve(samples.capacity() + additional);
+}
+void ClipVectorBuffer::append(float *b, int n) {
+    ensure(n);
+    for (int i = 0; i < n; i++) samples.push_back(b[i]);
+}
+float &ClipVectorBuffer::operator[](int i) { return samples[i]; }
+int ClipVectorBuffer::length() const { return (int)samples.size(); }
+float *ClipVectorBuffer::data() { return samples.data(); }
 
 Clip::Clip() : buf(nullptr), start(0), end(0), window(rectangular_window) {}
 Clip::Clip(ClipBuffer &b) : buf(&b), start(0), end(b.length()), window(rectangular_window) {}
@@ -250,6 +305,36 @@ struct DevClip {
     void store(Clip &c) { x.download(c.buf->data() + c.start, (size_t)L); }
 };
 }  // namespace
+
+// src/clip.cpp:128-143.  Not on the hot path: the right-hand clip is read through the const operator[] (its window applies)
+void Clip::operator+=(Clip &c) {
+    const Clip &r = c;
+    for (int i = 0; i < std::min(length(), c.length()); i++) (*this)[i] += r[i];
+}
+void Clip::operator-=(Clip &c) {
+    const Clip &r = c;
+    for (int i = 0; i < std::min(length(), c.length()); i++) (*this)[i] -= r[i];
+}
+void Clip::operator*=(Clip &c) {
+    const Clip &r = c;
+    for (int i = 0; i < std::min(length(), c.length()); i++) (*this)[i] *= r[i];
+}
+
+void Clip::dft(float *out, bool stack) const { partial_dft(out, length(), stack); }
+
+void Clip::partial_dft(float *out, int len, bool stack) const {
+    const int N = length();
+    if (len <= 0) return;
+    if (N < 2) throw srx_error(SRX_ERR_INVALID, "Clip::partial_dft: a window of fewer than two samples");
+    // the window is a host function pointer: its N/2 values are evaluated here (src/clip.cpp:124 evaluates them per access),
+    // the multiplication and everything after it run on the device
+    vector<float> w;
+    if (window != rectangular_window) {
+        w.resize((size_t)(N / 2));
+        for (int n = 0; n < N / 2; n++) w[(size_t)n] = window(n, N);
+    }
+    check(srx_partial_dft_frames(srx::context(), buf->data() + start, w.empty() ? nullptr : w.data(), N, len, 1, stack ? 1 : 0, out));
+}
 
 void Clip::operator*=(float f) {
     if (length() <= 0) return;
@@ -409,6 +494,94 @@ void featurevec::operator+=(featurevec &f) {
 }
 void featurevec::operator*=(float f) {
     for (int i = 0; i < FV_LEN; i++) (*this)[i] *= f;
+}
+
+float featurevec::dist(featurevec &f) {
+    float d = 0;
+    for (int i = 0; i < FV_LEN; i++) {
+        float diff = (*this)[i] - f[i];
+        d += diff * diff;
+    }
+    return std::sqrt(d);
+}
+featurevec featurevec::normalize(featurevec &mu, featurevec &var) {
+    featurevec res;
+    for (int i = 0; i < FV_LEN; i++) res[i] = ((*this)[i] - mu[i]) / std::sqrt(var[i]);
+    return res;
+}
+void featurevec::compute_deltas(vector<featurevec *> fvs, int i) {
+    int j = i - 1, k = i + 1;
+    if (j < 0) j = 0;
+    if (k == (int)fvs.size()) k--;
+    check(srx_delta(srx::context(), fvs[(size_t)k]->coeffs, fvs[(size_t)j]->coeffs, k - j, deltas, NPARAMS));
+}
+void featurevec::compute_delta2s(vector<featurevec *> fvs, int i) {
+    int j = i - 1, k = i + 1;
+    if (j < 0) j = 0;
+    if (k == (int)fvs.size()) k--;
+    check(srx_delta(srx::context(), fvs[(size_t)k]->deltas, fvs[(size_t)j]->deltas, k - j, delta2s, NPARAMS));
+}
+void compute_deltas(vector<featurevec *> fvs) {
+    const size_t n = fvs.size();
+    if (n == 0) return;
+    vector<float> raw(n * NPARAMS), feats(n * 3 * NPARAMS);
+    for (size_t i = 0; i < n; i++) std::memcpy(&raw[i * NPARAMS], fvs[i]->coeffs, NPARAMS * sizeof(float));
+    int64_t fo[2] = {0, (int64_t)n};
+    check(srx_features_batch(srx::context(), -1, NPARAMS, raw.data(), fo, 1, feats.data()));
+    for (size_t i = 0; i < n; i++) {
+        std::memcpy(fvs[i]->deltas, &feats[i * 3 * NPARAMS + NPARAMS], NPARAMS * sizeof(float));
+        std::memcpy(fvs[i]->delta2s, &feats[i * 3 * NPARAMS + 2 * NPARAMS], NPARAMS * sizeof(float));
+    }
+}
+
+float filter::operator()(float *spectrum) {
+    srx_filter f = {center, width, height};
+    const int n_bins = (int)(center + width) + 1;
+    if (n_bins <= 0) return 0.0f;   // the reference's loop body never runs
+    float res = 0;
+    check(srx_filterbank_apply(srx::context(), &f, 1, spectrum, n_bins, 1, &res));
+    return res;
+}
+float *filterbank::operator()(float *spectrum) {
+    vector<srx_filter> f;
+    int n_bins = 0;
+    for (const filter &x : filters) {
+        f.push_back({x.center, x.width, x.height});
+        n_bins = std::max(n_bins, (int)(x.center + x.width) + 1);
+    }
+    float *res = new float[filters.size() ? filters.size() : 1];
+    if (filters.empty()) return res;
+    try {
+        for (size_t i0 = 0; i0 < f.size(); i0 += 64) {   // the C ABI takes 64 filters per call
+            const int m = (int)std::min<size_t>(64, f.size() - i0);
+            check(srx_filterbank_apply(srx::context(), &f[i0], m, spectrum, n_bins, 1, res + i0));
+        }
+    } catch (...) {
+        delete[] res;
+        throw;
+    }
+    return res;
+}
+filterbank *linear_filterbank(float start, float step, int n, float width, int dft_bins, int sps) {
+    (void)step;   // src/mfcc.cpp:174 steps by n, not by `step`
+    filterbank *fb = new filterbank();
+    for (int i = 0; i < n; i++) fb->filters.push_back(filter(start + i * n, width, dft_bins, sps));
+    return fb;
+}
+float *dct(float *filtered, int len, int nparams) {
+    float *res = new float[nparams > 0 ? nparams : 1];
+    if (nparams <= 0) return res;
+    if (len <= 0) {   // the reference's inner loop never runs
+        for (int j = 0; j < nparams; j++) res[j] = 0;
+        return res;
+    }
+    try {
+        check(srx_dct(srx::context(), filtered, len, nparams, 1, res));
+    } catch (...) {
+        delete[] res;
+        throw;
+    }
+    return res;
 }
 
 filter::filter(float c, float w, int dft_bins, int sps) {
@@ -661,6 +834,60 @@ void gaussian::set_wt(float wt) {
     weight = wt;
     logwt = std::log(wt);
 }
+logprob_t gaussian::operator()(featurevec &fv) {
+    double m[FV_LEN], v[FV_LEN];
+    for (int i = 0; i < FV_LEN; i++) {
+        m[i] = (double)mean[i];
+        v[i] = (double)var[i];
+    }
+    float x[3 * NPARAMS], out = 0;
+    for (int i = 0; i < 3 * NPARAMS; i++) x[i] = fv[i];
+    check(srx_gaussian_logprob(srx::context(), x, 3 * NPARAMS, 1, FV_LEN, m, v, logwt, &out));
+    return out;
+}
+logprob_t gaussian::logprob(featurevec &fv) { return (*this)(fv); }
+prob_t gaussian::prob(featurevec &fv) { return expl((prob_t)(*this)(fv)); }
+void gaussian::clear() {
+    set_wt(1);
+    for (int i = 0; i < FV_LEN; i++) {
+        mean[i] = 0;
+        var[i] = 0;
+    }
+}
+void gaussian::divide_means() {
+    for (int i = 0; i < FV_LEN; i++) mean[i] /= zetasum;
+}
+void gaussian::divide_variances() {
+    for (int i = 0; i < FV_LEN; i++) var[i] /= zetasum;
+}
+void gaussian::blend(gaussian &g, float f) {
+    for (int i = 0; i < FV_LEN; i++) {
+        mean[i] = mean[i] * f + g.mean[i] * (1 - f);
+        var[i] = var[i] * f + g.var[i] * (1 - f);
+    }
+    set_wt(weight * f + g.weight * (1 - f));
+}
+logprob_t gmm::operator()(featurevec &fv) { return gaussians[0](fv); }
+void gmm::clear() {
+    for (gaussian &g : gaussians) g.clear();
+}
+void gmm::sum_zetas() {
+    zetasum = 0;
+    for (gaussian &g : gaussians) zetasum += g.zetasum;
+}
+void gmm::clear_zetas() {
+    zetasum = 0;
+    for (gaussian &g : gaussians) g.zetasum = 0;
+}
+void gmm::divide_means() {
+    for (gaussian &g : gaussians) g.divide_means();
+}
+void gmm::divide_variances() {
+    for (gaussian &g : gaussians) g.divide_variances();
+}
+void gmm::blend(gmm *o, float f) {
+    for (size_t i = 0; i < gaussians.size(); i++) gaussians[i].blend(o->gaussians[i], f);
+}
 gmm::gmm(int n) : gaussians(*new vector<gaussian>()), zetasum(0) {
     for (int i = 0; i < n; i++) gaussians.push_back(gaussian());
 }
@@ -712,19 +939,43 @@ void acoustic_model::initialize(featurevec &mu, featurevec &var) {
     for (acm_iter it = begin(); it != end(); it++) it->second->initialize(mu, var);
     host_dirty = true;
 }
+// The EM bookkeeping of src/gmm.cpp:188-229 on the host mirror (long double, as the reference); the device copy follows on
+// the next use.  The zeta sums live on the host objects only: hmm::train keeps its own on the device.
+void acoustic_model::clear() {
+    download();
+    for (acm_iter it = begin(); it != end(); it++) it->second->clear();
+    host_dirty = true;
+}
+void acoustic_model::sum_zetas() {
+    prob_t zetamax = 0;
+    acm_iter best = end();
+    for (acm_iter it = begin(); it != end(); it++) {
+        it->second->sum_zetas();
+        if (zetamax < it->second->zetasum) {
+            zetamax = it->second->zetasum;
+            best = it;
+        }
+    }
+    if (srx::verbose() && best != end())   // (the reference dereferences `best` even when no sum was positive)
+        std::cout << "Maximum zetasum: " << (double)zetamax << " for " << phone::names[best->first.curr] << std::endl;
+}
+void acoustic_model::clear_zetas() {
+    for (acm_iter it = begin(); it != end(); it++) it->second->clear_zetas();
+}
+void acoustic_model::divide_means() {
+    download();
+    for (acm_iter it = begin(); it != end(); it++) it->second->divide_means();
+    host_dirty = true;
+}
+void acoustic_model::divide_variances() {
+    download();
+    for (acm_iter it = begin(); it != end(); it++) it->second->divide_variances();
+    host_dirty = true;
+}
 void acoustic_model::blend(acoustic_model *a, float f) {
     download();
     a->download();
-    for (acm_iter it = begin(); it != end(); it++) {
-        vector<gaussian> &mine = it->second->gaussians, &theirs = a->mixtures[it->first]->gaussians;
-        for (size_t m = 0; m < mine.size(); m++) {
-            for (int i = 0; i < FV_LEN; i++) {
-                mine[m].mean[i] = mine[m].mean[i] * f + theirs[m].mean[i] * (1 - f);
-                mine[m].var[i] = mine[m].var[i] * f + theirs[m].var[i] * (1 - f);
-            }
-            mine[m].set_wt(mine[m].weight * f + theirs[m].weight * (1 - f));
-        }
-    }
+    for (acm_iter it = begin(); it != end(); it++) it->second->blend(a->mixtures[it->first], f);
     host_dirty = true;
 }
 srx_model *acoustic_model::device() {

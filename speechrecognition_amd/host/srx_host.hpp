@@ -14,15 +14,21 @@
 //   hmm.hpp    hmm_state, state_model, hmm (training-HMM constructor, viterbi, train_transition_probabilities,
 //              train, update_states)
 //   utterance.hpp  utterance, mean, variance
-// Not mirrored (outside the hot path): ofApp, cluster, langmodel, the
-// lexicon-HMM constructor, the microphone ClipBuffer constructors, filter::operator() / filterbank::operator()
-// / dct / Clip::partial_dft as stand-alone per-frame host calls (they exist only fused inside the MFCC kernel).
+// Not mirrored (outside the hot path): ofApp, cluster, the bigram model, the microphone
+// (ofSoundBuffer) ClipBuffer constructors, hanning_window / rand_gaussian / random_fv / min / max / argmax / convolve.
+// Every per-frame function of the path -- Clip::partial_dft / dft, filter::operator(), filterbank::operator(), log(buf, len),
+// dct, featurevec::compute_deltas / compute_delta2s, gaussian::operator() / logprob / prob, gmm::operator() -- is one call
+// into a reference-order kernel of libsrx (csrc/srx_frameops.hip); the fused batch kernels stay the fast path.
+// The EM bookkeeping of gaussian / gmm / acoustic_model (clear, clear_zetas, sum_zetas, divide_means, divide_variances,
+// blend) works on the host mirror in long double, as the reference does: it is O(parameters), never O(frames), and the
+// 80-bit type has no device form; hmm::train does the same steps on the device (srx_em_means_dev / srx_em_finish_dev).
 //
 // Additions with no counterpart in the reference are marked [batch]: they hand a whole ragged batch to one
 // kernel launch, which is where the throughput comes from (the reference loops utterance by utterance).
 #ifndef SRX_HOST_HPP
 #define SRX_HOST_HPP
 
+#include <cstdint>
 #include <exception>
 #include <istream>
 #include <list>
@@ -69,6 +75,12 @@ srx_ctx *context();            // the process-wide context (device SRX_DEVICE or
 // utterances; hmm::train, mean and variance complete their sums over all ranks through this communicator.
 void init_distributed();       // joins the launch described by RANK / WORLD_SIZE / LOCAL_RANK (+ SRX_COMM_FILE); no-op without
 srx_comm *communicator();      // world-1 communicator (collectives are no-ops) unless init_distributed joined a launch
+// The id rendezvous of init_distributed, as three host-only steps (file I/O; tested without a GPU).  The file holds a
+// magic word, a nonce that every rank of ONE launch computes alike, and rank 0's SRX_COMM_ID_BYTES: a file left behind by
+// an earlier launch (or by anything else) does not carry this launch's nonce and is ignored by the waiting ranks.
+uint64_t launch_nonce();       // from SRX_COMM_NONCE, TORCHELASTIC_RUN_ID, MASTER_ADDR, MASTER_PORT, WORLD_SIZE
+void publish_comm_id(const std::string &file, uint64_t nonce, const unsigned char *id);      // rank 0: unlink, write .tmp, rename
+bool await_comm_id(const std::string &file, uint64_t nonce, unsigned char *id, int timeout_ms);   // ranks > 0
 int rank();
 int world();
 std::vector<int> shard_utterances(const std::vector<double> &costs, int world, int rank);   // this rank's utterance indices
@@ -83,6 +95,8 @@ std::vector<std::string> readlines(const char *fname);                          
 inline std::vector<std::string> readlines(const std::string &f) { return readlines(f.c_str()); }
 float hamming_window(int x, int len);                                                    // src/utils.cpp:21-23
 float rectangular_window(int x, int len);                                                // src/utils.cpp:13-15
+// log(T *buf, int len) for T = float, src/utils.hpp:55-60: buf[i] = log(buf[i] + 1), in place           (GPU: k_log1p)
+void log(float *buf, int len);
 
 // ------------------------------------------------------------------------------------------ clip.hpp
 class ClipBuffer {                                                                       // src/clip.hpp:22-30
@@ -104,6 +118,17 @@ public:
     float *data();
 };
 
+class ClipVectorBuffer : public ClipBuffer {                                             // src/clip.hpp:49-64
+    std::vector<float> samples;
+public:
+    ClipVectorBuffer();
+    void append(float *buf, int n);           // src/clip.cpp:62-66 (the ofSoundBuffer overload is not mirrored)
+    void ensure(int n);
+    float &operator[](int i);
+    int length() const;
+    float *data();
+};
+
 class Clip {                                                                             // src/clip.hpp:66-96
 public:
     ClipBuffer *buf;
@@ -117,10 +142,17 @@ public:
     float &operator[](int idx);               // src/clip.cpp:118-120
     float operator[](int idx) const;          // src/clip.cpp:123-125 (applies the window)
     int length() const;
+    void operator+=(Clip &c);                 // src/clip.cpp:128-143: sample-wise over min(length, c.length); the right-hand
+    void operator-=(Clip &c);                 //   side is read through ITS window.  Not on the hot path (the reference never
+    void operator*=(Clip &c);                 //   calls them from main): plain host loops.
     void operator*=(float f);                 // src/clip.cpp:144-148           (GPU)
     void normalizeVolume(float targetRMS);    // src/clip.cpp:151-154           (GPU: k_sumsq_scale + k_apply_scale)
     double rmsAmplitude() const;              // src/clip.cpp:157-164           (GPU: k_rms)
     void preemphasis(float alpha);            // src/clip.cpp:199-205           (GPU: k_preemph)
+    void dft(float *out, bool stack = false) const;                  // src/clip.cpp:166-168
+    // src/clip.cpp:174-194: the first `len` magnitudes over the first half of the window, through this clip's window
+    // function; len > length()/2 also writes the mirrored bins; `stack` adds to `out`.          (GPU: k_partial_dft_exact)
+    void partial_dft(float *out, int len, bool stack = false) const;
 };
 
 // ------------------------------------------------------------------------------------------ wav.hpp
@@ -145,13 +177,20 @@ public:
     float &operator[](int i);                 // 0..3*NPARAMS-1 across the three arrays, src/mfcc.cpp:30-38
     void operator+=(featurevec &);            // first FV_LEN entries, src/mfcc.cpp:40-44
     void operator*=(float);
+    float dist(featurevec &f);                                        // src/mfcc.cpp:52-59   (k-means only: host)
+    featurevec normalize(featurevec &mu, featurevec &sigma);          // src/mfcc.cpp:64-70   (k-means only: host)
+    void compute_deltas(std::vector<featurevec *> fvs, int i);        // src/mfcc.cpp:73-81   (GPU: k_delta)
+    void compute_delta2s(std::vector<featurevec *> fvs, int i);       // src/mfcc.cpp:84-92   (GPU: k_delta)
 };
+// src/mfcc.cpp:95-102: deltas of every vector, then delta-deltas of every vector                   (GPU: k_features, WL = -1)
+void compute_deltas(std::vector<featurevec *> fvs);
 
 class filter {                                                                           // src/mfcc.hpp:50-60
 public:
     float center, width, height;
     filter(float c, float w, int dft_bins = 256, int sps = 16000);   // src/mfcc.cpp:117-128
     float get(int bin) const;                                        // src/mfcc.cpp:132-140
+    float operator()(float *spectrum);                               // src/mfcc.cpp:143-149   (GPU: k_filterbank_exact)
 };
 
 class filterbank {                                                                       // src/mfcc.hpp:62-72
@@ -159,7 +198,13 @@ public:
     std::vector<filter> filters;
     filterbank();
     int length() const;
+    float *operator()(float *spectrum);       // src/mfcc.cpp:161-167: new float[length()], caller delete[]s   (GPU: k_filterbank_exact)
 };
+
+// src/mfcc.cpp:171-177 (start + i*n as the reference has it, not start + i*step)
+filterbank *linear_filterbank(float start, float step, int n, float width, int dft_bins = 256, int sps = 16000);
+// src/mfcc.cpp:205-214: new float[nparams], caller delete[]s                                       (GPU: k_dct_exact)
+float *dct(float *filtered, int len, int nparams);
 
 filterbank *mel_filterbank(float end, int n, int dft_bins = 256, int sps = 16000);       // src/mfcc.cpp:190-201
 // One frame: `c` is the window (c.length() = window length).  Returns new float[NPARAMS]; caller delete[]s
@@ -255,6 +300,13 @@ public:
     gaussian();
     void initialize(featurevec &mu, featurevec &sigma2);   // src/gmm.cpp:26-33 (srx::seed_random stands in for ofRandom's generator)
     void set_wt(float wt);                                 // src/gmm.cpp:35-38
+    logprob_t operator()(featurevec &fv);                  // src/gmm.cpp:41-49   (GPU: k_gaussian_exact)
+    prob_t prob(featurevec &fv);                           // src/gmm.cpp:57-59: exp((prob_t) of the above)
+    logprob_t logprob(featurevec &fv);                     // src/gmm.cpp:52-54
+    void clear();                                          // src/gmm.cpp:61-67
+    void divide_means();                                   // src/gmm.cpp:69-73
+    void divide_variances();                               // src/gmm.cpp:75-79
+    void blend(gaussian &g, float f);                      // src/gmm.cpp:82-88
 };
 
 class gmm {                                                                              // src/gmm.hpp:48-72
@@ -263,7 +315,14 @@ public:
     prob_t zetasum;
     gmm(int n);
     gmm(gmm *g);
+    logprob_t operator()(featurevec &fv);                  // src/gmm.cpp:99-100: component 0, as the reference is compiled
     void initialize(featurevec &, featurevec &);
+    void clear();                                          // src/gmm.cpp:119-154
+    void sum_zetas();
+    void clear_zetas();
+    void divide_means();
+    void divide_variances();
+    void blend(gmm *g, float f);
 };
 
 typedef std::map<phone::context, gmm *>::iterator acm_iter;
@@ -277,7 +336,12 @@ public:
     ~acoustic_model();
     logprob_t operator()(featurevec &fv, phone::context ph);   // src/gmm.cpp:184-186 (one frame, one state; GPU)
     void initialize(featurevec &, featurevec &);           // src/gmm.cpp:177-181
-    void blend(acoustic_model *a, float f);                // src/gmm.cpp:221-225 (host mirror only)
+    void clear();                                          // src/gmm.cpp:188-223: each loops over the mixtures (host mirror)
+    void sum_zetas();                                      //   (prints the maximum zeta sum when srx::set_verbose(true))
+    void clear_zetas();
+    void divide_means();
+    void divide_variances();
+    void blend(acoustic_model *a, float f);                // src/gmm.cpp:225-229 (host mirror)
     acm_iter begin();
     acm_iter end();
 

@@ -144,6 +144,85 @@ int main(int argc, char **argv) {
         vector<featurevec *> few(fvs.begin(), fvs.begin() + 4);
         path none = h.viterbi(few, prevp, 1e10);   // 4 frames cannot reach state 10
         printf("no_path_len %zu\n", none.size());
+        // ---- the per-frame functions of clip.hpp / mfcc.hpp / gmm.hpp, call by call ----
+        Clip fr(wav, 160 * 5, 160 * 5 + 320);           // pre-emphasised samples by now
+        dump("fr_samples", wav.buf->data() + 160 * 5, 320);
+        fr.window = hamming_window;
+        float spec[144];
+        fr.partial_dft(spec, 144);                      // src/clip.cpp:174-194, as mfcc() calls it (src/mfcc.cpp:223)
+        dump("pd_spec", spec, 144);
+        float acc[144];
+        for (int i = 0; i < 144; i++) acc[i] = 0.001f * i;
+        fr.partial_dft(acc, 144, true);                 // stack
+        dump("pd_stack", acc, 144);
+        Clip small(wav, 1000, 1000 + 64);               // rectangular window, every bin: the mirrored writes
+        dump("small_samples", wav.buf->data() + 1000, 64);
+        float full[64];
+        small.dft(full);
+        dump("dft64", full, 64);
+        float *filt = fbank(spec);                      // filterbank::operator(), src/mfcc.cpp:161-167
+        dump("fb", filt, 48);
+        printf("fb7 %.9g\n", (double)fbank.filters[7](spec));   // filter::operator(), src/mfcc.cpp:143-149
+        log(filt, fbank.length());                      // src/utils.hpp:55-60
+        dump("logfb", filt, 48);
+        float *cc = dct(filt, fbank.length(), NPARAMS); // src/mfcc.cpp:205-214
+        dump("dct", cc, NPARAMS);
+        delete[] cc;
+        delete[] filt;
+        filterbank *lin = linear_filterbank(100, 50, 3, 200, 320, 16000);   // src/mfcc.cpp:171-177 (steps by n)
+        printf("linfb");
+        for (filter &q : lin->filters) printf(" %.9g %.9g %.9g", (double)q.center, (double)q.width, (double)q.height);
+        printf("\n");
+        // compute_deltas(vector) and the per-vector members, src/mfcc.cpp:73-102
+        vector<featurevec *> cp;
+        for (int i = 0; i < 6; i++) cp.push_back(new featurevec(fvs[i]->coeffs));
+        compute_deltas(cp);
+        dump("cd0_delta", cp[0]->deltas, NPARAMS);
+        dump("cd3_delta2", cp[3]->delta2s, NPARAMS);
+        featurevec lone(cp[2]->coeffs);
+        lone.compute_deltas(cp, 2);
+        lone.compute_delta2s(cp, 5);
+        dump("lone_delta", lone.deltas, NPARAMS);
+        dump("lone_delta2", lone.delta2s, NPARAMS);
+        printf("dist %.9g\n", (double)cp[1]->dist(*cp[4]));
+        // gaussian / gmm as objects of their own, src/gmm.cpp:41-59, 99-100
+        gaussian gz;
+        for (int i = 0; i < FV_LEN; i++) {
+            gz.mean[i] = (*fvs[9])[i];
+            gz.var[i] = 0.5 + 0.1 * i;
+        }
+        gz.set_wt(0.3f);
+        printf("gauss %.9g %.9g %.17Lg\n", (double)gz(*fvs[4]), (double)gz.logprob(*fvs[4]), gz.prob(*fvs[4]));
+        gmm gm(2);
+        gm.gaussians[0] = gz;
+        printf("gmm0 %.9g\n", (double)gm(*fvs[4]));
+        // EM bookkeeping on the objects, src/gmm.cpp:61-88, 119-154, 188-229
+        gaussian ga = gz, gb;
+        ga.zetasum = 4;
+        ga.divide_means();
+        ga.divide_variances();
+        printf("div %.17Lg %.17Lg\n", ga.mean[3], ga.var[3]);
+        gb.blend(ga, 0.25f);
+        printf("blend %.17Lg %.17Lg %.9g %.9g\n", gb.mean[3], gb.var[3], (double)gb.weight, (double)gb.logwt);
+        gm.gaussians[0].zetasum = 1.5;
+        gm.gaussians[1].zetasum = 2.25;
+        gm.sum_zetas();
+        printf("zsum %.17Lg\n", gm.zetasum);
+        gm.clear_zetas();
+        gm.clear();
+        printf("cleared %.17Lg %.17Lg %.17Lg %.9g\n", gm.zetasum, gm.gaussians[0].mean[0], gm.gaussians[0].var[0], (double)gm.gaussians[0].weight);
+        acoustic_model acm2(&acm);
+        for (acm_iter it = acm2.begin(); it != acm2.end(); it++) it->second->gaussians[0].zetasum = 2;
+        acm2.sum_zetas();
+        acm2.divide_means();
+        acm2.divide_variances();
+        acm2.blend(&acm, 0.5f);       // 0.5 * (param / 2) + 0.5 * param
+        printf("acm_blend %.17Lg %.17Lg\n", acm2.begin()->second->gaussians[0].mean[2] / acm.begin()->second->gaussians[0].mean[2],
+               acm2.begin()->second->gaussians[0].var[2] / acm.begin()->second->gaussians[0].var[2]);
+        printf("acm_blend_score %.9g\n", (double)acm2(*fvs[3], h.states[2].ctx));   // the device copy follows the host edit
+        acm2.clear_zetas();
+        acm2.clear();
+        printf("acm_cleared %.17Lg %.9g\n", acm2.begin()->second->gaussians[0].var[5], (double)acm2.begin()->second->gaussians[0].weight);
         delete wav.buf;
     } catch (srx_error &e) {
         printf("srx_error %d %s\n", e.code, e.what());

@@ -293,6 +293,43 @@ int main(int argc, char **argv) {
     }
     puts("ok sharding");
 
+    // ---- id rendezvous of srx::init_distributed: a file of an earlier launch must not be taken for this one's ----
+    {
+        const string file = tmp + "srx.id";
+        unsigned char old_id[SRX_COMM_ID_BYTES], new_id[SRX_COMM_ID_BYTES], got[SRX_COMM_ID_BYTES];
+        memset(old_id, 0x11, sizeof old_id);
+        memset(new_id, 0x22, sizeof new_id);
+        setenv("MASTER_PORT", "29500", 1);
+        setenv("WORLD_SIZE", "2", 1);
+        const uint64_t old_nonce = srx::launch_nonce();
+        setenv("MASTER_PORT", "29517", 1);
+        const uint64_t nonce = srx::launch_nonce();
+        CHECK(nonce != old_nonce && nonce == srx::launch_nonce());
+        setenv("SRX_COMM_NONCE", "job-42", 1);
+        CHECK(srx::launch_nonce() != nonce);
+        unsetenv("SRX_COMM_NONCE");
+        srx::publish_comm_id(file, old_nonce, old_id);                      // the stale file of a crashed launch
+        CHECK(!srx::await_comm_id(file, nonce, got, 50));                   // not ours: keep waiting (here: time out)
+        put_file(file, string((const char *)old_id, sizeof old_id));        // a bare id, as an older build wrote it
+        CHECK(!srx::await_comm_id(file, nonce, got, 30));
+        put_file(file, string("SRXCOMM1"));                                  // a partial file
+        CHECK(!srx::await_comm_id(file, nonce, got, 30));
+        srx::publish_comm_id(file, nonce, new_id);                           // rank 0 of this launch replaces it
+        CHECK(srx::await_comm_id(file, nonce, got, 1000) && !memcmp(got, new_id, sizeof got));
+        remove(file.c_str());
+        CHECK(!srx::await_comm_id(file, nonce, got, 20));                   // no file at all
+        bool threw = false;
+        try {
+            srx::publish_comm_id(tmp + "no/such/dir/srx.id", nonce, new_id);
+        } catch (srx_error &e) {
+            threw = e.code == SRX_ERR_IO;
+        }
+        CHECK(threw);
+        unsetenv("MASTER_PORT");
+        unsetenv("WORLD_SIZE");
+    }
+    puts("ok rendezvous");
+
     // ---- host-side state bookkeeping ----
     {
         featurevec a, b;

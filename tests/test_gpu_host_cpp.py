@@ -146,6 +146,41 @@ def test_host_api_calls_match_oracle(oracle, tmp_path):
     assert rl["status"] == 0 and [int(v) for v in d["lex_path_after"]] == list(rl["path"])
     assert abs(f("lex_decode_prevp")[1] - float(rl["final"]) / len(feats)) <= 1e-6 * abs(float(rl["final"]) / len(feats))
     assert f("lex_decode_prevp")[0] != f("lex_decode_prevp")[1]
+    # ---- the per-frame functions, call by call, on the samples the C++ side printed (bit-exact unless noted) ----
+    f32 = lambda k: np.array([np.float32(v) for v in d[k]], np.float32)
+    fr = f32("fr_samples")
+    ham = np.array([oracle.hamming(k, 320) for k in range(160)], np.float32)
+    spec = oracle.partial_dft_win(fr, ham, 320, 144)
+    assert f32("pd_spec").tobytes() == spec.tobytes()
+    acc0 = (np.float32(0.001) * np.arange(144, dtype=np.float32)).astype(np.float32)
+    assert f32("pd_stack").tobytes() == oracle.partial_dft_win(fr, ham, 320, 144, stack=True, out=acc0).tobytes()
+    assert f32("dft64").tobytes() == oracle.partial_dft_win(f32("small_samples"), None, 64, 64).tobytes()
+    filt = oracle.filterbank_apply(fb, spec)
+    assert f32("fb").tobytes() == filt.tobytes() and f32("fb7")[0] == filt[7]
+    lf = oracle.log1p(filt)
+    got_lf = f32("logfb")
+    assert np.abs(got_lf.view(np.int32).astype(np.int64) - lf.view(np.int32).astype(np.int64)).max() <= 1   # device logf vs glibc
+    assert f32("dct").tobytes() == oracle.dct(got_lf, 13).tobytes()
+    lin = f32("linfb").reshape(3, 3)       # linear_filterbank steps by n = 3 Hz, not by `step` (src/mfcc.cpp:174)
+    np.testing.assert_allclose(lin[:, 0], (np.float32(100) + np.arange(3, dtype=np.float32) * 3) / np.float32(16000) * np.float32(320), rtol=1e-6)
+    cd = oracle.compute_deltas(feats[:6, :13])
+    assert f32("cd0_delta").tobytes() == cd[0, 13:26].tobytes() and f32("cd3_delta2").tobytes() == cd[3, 26:].tobytes()
+    assert f32("lone_delta").tobytes() == cd[2, 13:26].tobytes() and f32("lone_delta2").tobytes() == cd[5, 26:].tobytes()
+    assert abs(f("dist")[0] - np.sqrt(((feats[1, :13] - feats[4, :13]) ** 2).sum())) <= 1e-5 * f("dist")[0]
+    gmean, gvar = feats[9, :13].astype(np.float64), 0.5 + 0.1 * np.arange(13)
+    glw = oracle.set_wt(np.array([0.3], np.float32))[0]
+    gref = oracle.gaussian_logprob(feats[4, :13], gmean, gvar, glw)
+    g = f("gauss")
+    assert abs(g[0] - gref) <= 1e-6 * max(1, abs(gref)) and g[0] == g[1] and f("gmm0")[0] == g[0]
+    assert abs(g[2] - np.exp(np.longdouble(np.float32(g[0])))) <= 1e-15 * g[2]
+    np.testing.assert_allclose(f("div"), [gmean[3] / 4, gvar[3] / 4], rtol=1e-15)
+    w_bl = np.float32(np.float32(1) * np.float32(0.25) + np.float32(0.3) * np.float32(0.75))
+    np.testing.assert_allclose(f("blend"), [0 * 0.25 + gmean[3] / 4 * 0.75, 1 * 0.25 + gvar[3] / 4 * 0.75, w_bl, np.log(w_bl)], rtol=1e-6)
+    assert f("zsum")[0] == 3.75 and list(f("cleared")) == [0, 0, 0, 1]
+    np.testing.assert_allclose(f("acm_blend"), [0.75, 0.75], rtol=1e-15)
+    e_bl = oracle.gmm_score(feats[3:4], mean * 0.75, var * 0.75, lw, 13, 0)[0, ph[2]]
+    assert abs(f("acm_blend_score")[0] - e_bl) <= 1e-6 * max(1, abs(e_bl))
+    assert list(f("acm_cleared")) == [0, 1]
     mu, var = oracle.corpus_mean_var(feats, 13)   # reference: f32 running sums; device: f64 sums
     np.testing.assert_allclose(f("corpus_mean"), mu, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(f("corpus_var"), var, rtol=1e-4)
