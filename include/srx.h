@@ -409,6 +409,29 @@ int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const float *feat
 int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats1_dev, const double *stats2_dev,
                       float blend_keep);
 
+/* The same statistics in ONE pass and ONE exchange (round 3; the five steps above stay as the rounding-faithful form).
+ * With x' = x - c (c = the state's centre: the mean of its component means under A, identical on every rank)
+ *     S0 = sum zeta,  S1 = sum zeta x',  S2 = sum zeta x'^2   ->   mean = c + S1/S0,  var = S2/S0 - (S1/S0)^2
+ * which is the reference's sum zeta (x - NEW mean)^2 / sum zeta (src/hmm.cpp:318-339) without its rounding of (x - mean) to f32
+ * (src/hmm.cpp:331: a relative difference of parts in 1e8 on a variance) and without a second sweep over the frames.
+ * srx_em_fused_dev sorts the frames by state and accumulates [S1 | S0 | S2 | frame count] per (state, component) on the f64
+ * matrix cores into stats12[srx_em_fused_len(A)] (all-reduce SUM it across ranks); srx_em_fused_finish_dev rebuilds B from it
+ * and blends with A.  Two modes:
+ *   logp_dev / shift_dev given (from srx_em_shift_dev, shift all-reduced MAX): zeta from the rounding-faithful log-densities;
+ *       only the variance formula differs from the five-step form (means, weights: same sums).
+ *   logp_dev == shift_dev == NULL: the log-densities are evaluated on the matrix cores too, in f64 WITHOUT the reference's f32
+ *       roundings of gaussian::operator() (src/gmm.cpp:44-47), relative to each component's peak density (no data-dependent shift:
+ *       no pre-pass, no MAX exchange).  zeta then differs from the reference's by the reference's own f32 noise (~1e-6 relative per
+ *       frame).  *underflow_dev (may be NULL) receives the number of components that saw frames but whose zeta sum fell below
+ *       1e-290 (every frame tens of standard deviations away: the reference's 80-bit exponent holds those, f64 relative to the
+ *       peak does not): when it is non-zero, repeat the iteration's statistics through the five steps above.
+ * Shapes: M <= 16, D <= 39, G <= 16383 (srx_em_fused_len returns 0 otherwise). */
+int64_t srx_em_fused_len(const srx_model *A);
+int srx_em_fused_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
+                     const float *logp_dev, const float *shift_dev, double *stats12_dev);
+int srx_em_fused_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats12_dev, const float *shift_dev,
+                            float blend_keep, int32_t *underflow_dev);
+
 /* ---------------------------------------------------------------- multi-GPU exchange --- */
 /* One process per GPU, utterances sharded across the ranks; MFCC, scoring and alignment need no communication.  What
  * the ranks exchange are the sums that the reference's sequential loops over all utterances build:

@@ -120,6 +120,9 @@ SIGNATURES = {
     "srx_em_means_dev": (C.c_int, [vp, vp, vp, vp]),
     "srx_em_pass2_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, i64, vp, vp, vp]),
     "srx_em_finish_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_float]),
+    "srx_em_fused_len": (i64, [vp]),
+    "srx_em_fused_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, i64, vp, vp, vp]),
+    "srx_em_fused_finish_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, vp]),
     "srx_comm_unique_id": (C.c_int, [vp]),
     "srx_comm_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "srx_comm_create_host": (C.c_int, [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),

@@ -227,6 +227,8 @@ template <int PASS>
 int srx_em_accum_seg(srx_ctx *ctx, const float *feats, int ld, const int32_t *gid, int64_t T, int G, int M, int D, const float *weight,
                      const float *logp, const float *shift, const double *meanB, double *stats);
 
+static int ensure_lconst(srx_ctx *ctx, srx_model *A);
+
 extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
                                 float *logp_dev, float *shift_dev) {
     SRX_ENTER(ctx, "srx_em_shift_dev");
@@ -245,15 +247,9 @@ extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
         int rc = srx_em_seg_sort(ctx, gid_dev, T, A->G);
         if (rc != SRX_OK) return rc;
     }
-    if (A->lconst_version != A->version || !A->lconst) {
-        const int64_t nl = (int64_t)A->G * A->M * A->D;
-        if (!A->lconst) SRX_HIP(ctx, hipMalloc((void **)&A->lconst, (size_t)2 * nl * sizeof(double)));
-        {
-            SrxProf prof_(ctx, "k_model_lconst");
-            hipLaunchKernelGGL(k_model_lconst, dim3((unsigned)ceil_div64(nl, 256)), dim3(256), 0, ctx->stream, A->var, nl, A->lconst);
-        }
-        SRX_LAUNCH_CHECK(ctx);
-        A->lconst_version = A->version;
+    {
+        int rc = ensure_lconst(ctx, A);
+        if (rc != SRX_OK) return rc;
     }
     if (seg)
         return srx_em_logp_seg(ctx, feats_dev, ld, T, A->G, A->M, A->D, A->mean, A->lconst + (size_t)A->G * A->M * A->D, A->lconst, A->logwt,
@@ -330,6 +326,61 @@ extern "C" int srx_em_pass2_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const 
                 "srx_em_pass2_dev: bad argument");
     SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_pass2_dev: model shape mismatch");
     return launch_accum<2>(ctx, A, B, feats_dev, ld, gid_dev, T, logp_dev, shift_dev, stats2_dev);
+}
+
+// srx_train_seg.hip
+bool srx_em_fused_applicable(int G, int M, int D);
+int srx_em_fused_row(int D);
+int srx_em_fused_launch(srx_ctx *ctx, const float *feats, int ld, const int32_t *gid, int64_t T, int G, int M, int D, const double *meanA,
+                        const double *rvarA, const float *weight, const float *logp, const float *shift, double *stats);
+int srx_em_fused_finish_launch(srx_ctx *ctx, int G, int M, int D, const double *stats, const float *shift, const double *meanA,
+                               const double *varA, const float *wA, const float *lwA, double *meanB, double *varB, float *wB, float *lwB,
+                               float keep, int32_t *underflow);
+
+static int ensure_lconst(srx_ctx *ctx, srx_model *A) {
+    if (A->lconst_version != A->version || !A->lconst) {
+        const int64_t nl = (int64_t)A->G * A->M * A->D;
+        if (!A->lconst) SRX_HIP(ctx, hipMalloc((void **)&A->lconst, (size_t)2 * nl * sizeof(double)));
+        {
+            SrxProf prof_(ctx, "k_model_lconst");
+            hipLaunchKernelGGL(k_model_lconst, dim3((unsigned)ceil_div64(nl, 256)), dim3(256), 0, ctx->stream, A->var, nl, A->lconst);
+        }
+        SRX_LAUNCH_CHECK(ctx);
+        A->lconst_version = A->version;
+    }
+    return SRX_OK;
+}
+
+extern "C" int64_t srx_em_fused_len(const srx_model *A) {
+    if (!A || !srx_em_fused_applicable(A->G, A->M, A->D)) return 0;
+    return (int64_t)A->G * A->M * srx_em_fused_row(A->D);
+}
+
+extern "C" int srx_em_fused_dev(srx_ctx *ctx, srx_model *A, const float *feats_dev, int ld, const int32_t *gid_dev, int64_t T,
+                                const float *logp_dev, const float *shift_dev, double *stats12_dev) {
+    SRX_ENTER(ctx, "srx_em_fused_dev");
+    SRX_REQUIRE(ctx, A && feats_dev && gid_dev && stats12_dev && T >= 0 && ld >= A->D, "srx_em_fused_dev: bad argument");
+    SRX_REQUIRE(ctx, (logp_dev == nullptr) == (shift_dev == nullptr), "srx_em_fused_dev: logp_dev and shift_dev go together");
+    SRX_REQUIRE(ctx, srx_em_fused_applicable(A->G, A->M, A->D),
+                "srx_em_fused_dev: needs M <= 16, D <= 39, G <= 16383 (have M %d, D %d, G %d); use the srx_em_shift/pass1/pass2 steps", A->M, A->D,
+                A->G);
+    int rc = ensure_lconst(ctx, A);
+    if (rc != SRX_OK) return rc;
+    return srx_em_fused_launch(ctx, feats_dev, ld, gid_dev, T, A->G, A->M, A->D, A->mean, A->lconst + (size_t)A->G * A->M * A->D, A->weight,
+                               logp_dev, shift_dev, stats12_dev);
+}
+
+extern "C" int srx_em_fused_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats12_dev, const float *shift_dev,
+                                       float blend_keep, int32_t *underflow_dev) {
+    SRX_ENTER(ctx, "srx_em_fused_finish_dev");
+    SRX_REQUIRE(ctx, A && B && stats12_dev, "srx_em_fused_finish_dev: null argument");
+    SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_fused_finish_dev: model shape mismatch");
+    SRX_REQUIRE(ctx, srx_em_fused_applicable(A->G, A->M, A->D), "srx_em_fused_finish_dev: shape outside the fused path");
+    int rc = srx_em_fused_finish_launch(ctx, A->G, A->M, A->D, stats12_dev, shift_dev, A->mean, A->var, A->weight, A->logwt, B->mean, B->var,
+                                        B->weight, B->logwt, blend_keep, underflow_dev);
+    if (rc != SRX_OK) return rc;
+    B->version++;
+    return SRX_OK;
 }
 
 extern "C" int srx_em_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const double *stats1_dev, const double *stats2_dev,

@@ -474,6 +474,237 @@ __global__ __launch_bounds__(64) void k_em_accum1_mfma(const float *__restrict__
         }
 }
 
+// ---- the fused statistics kernel (round 3) --------------------------------------------------------------------------
+// Everything hmm::train takes from an aligned frame (src/hmm.cpp:274-339: zeta, zeta * x, zeta * (x - mean)^2) in ONE pass on the
+// f64 matrix cores, with the variance pass folded into the first: with x' = x - c (c = the state's centre, below)
+//     S0 = sum zeta,   S1 = sum zeta x',   S2 = sum zeta x'^2      ->  mean = c + S1/S0,   var = S2/S0 - (S1/S0)^2
+// which is sum zeta (x - mean)^2 / S0 for mean = the NEW mean, as src/hmm.cpp:318-334 has it -- without the reference's rounding
+// of (x - mean) to f32 (src/hmm.cpp:331), which moves a variance by parts in 1e8, and without a second sweep over the frames or
+// a third exchange between ranks.  Centring on c (the average of the state's component means under A: the same numbers on every
+// rank) keeps the subtraction S2/S0 - (S1/S0)^2 away from cancellation: |mean - c| is a few standard deviations, not |mean|.
+//
+// One wave per work item (<= CH frames of one state), 16 frames per step.  xx[f] = [x'_0 .. x'_{D-1}, 1, 0.. | x'^2_0 .. x'^2_{D-1}, 0..]
+// (two halves of H = 8 NCT columns).  LOGP_MFMA: the log-densities themselves come off the matrix cores,
+//     logp_m(x) - peak_m = sum_d ( -1/2 rv_d x'^2_d + rv_d mu'_d x'_d - 1/2 rv_d mu'^2_d ),   mu' = mean_m - c,  rv = 1 / var,
+// as L^T [16 frames x 16 components] = xx [16 x 2H] . W^T [2H x 16] (4 NCT v_mfma_f64_16x16x4_f64), where peak_m = logp_m(mean_m) is
+// the density's maximum: zeta' = w exp(logp - peak) <= w needs no data-dependent shift (no pre-pass over the frames, no MAX
+// exchange) and the peak is re-applied where the mixture weights are formed.  The D lane of that product holds L for frames
+// kq + 4r (kq = lane >> 4) of component lane & 15 -- exactly the A operand of the accumulation
+//     stats[m][col] += sum_f zeta[m][f] xx[f][col]         (4 NCT more MFMAs: K = the 16 frames, four at a time, NCT column groups)
+// so zeta never moves between lanes.  The frame rows are read once from HBM (each lane 2 NCT values of frame lane & 15, which are
+// its A operand of the first product), centred, and pass through a 16 x H f64 tile in LDS to reach the lanes that need them as
+// B operand of the second.  !LOGP_MFMA: zeta from log-densities given (srx_em_shift_dev: the rounding-faithful ones), only
+// the accumulation runs here.  Column group c of the accumulation holds x' of dimensions 8c .. 8c+7 in lanes 0-7 and their
+// squares in lanes 8-15.  Row layout of the result: [0, D) S1, D: S0, H + [0, D): S2, H + D: the number of frames (for the
+// underflow test of k_em_fused_finish).
+static constexpr int FUSED_NCT_MAX = 5;   // D + 1 <= 8 * NCT: D <= 39
+
+template <int NCT, bool LOGP_MFMA>
+__global__ __launch_bounds__(64, 2) void k_em_fused(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
+                                                    const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G, int M,
+                                                    int D, const double *__restrict__ meanA, const double *__restrict__ rvarA,
+                                                    const float *__restrict__ weight, const float *__restrict__ logp_in,
+                                                    const float *__restrict__ shift_in, double *__restrict__ partial) {
+    constexpr int H = 8 * NCT, K = 2 * H, NV = 2 * NCT;   // NV: values of a frame row per lane (columns 4 kk + kq)
+    __shared__ double xs[16][H + 1];
+    __shared__ double cs[H];
+    const int item = blockIdx.x;
+    if (item >= item_start[G]) return;
+    int lo = 0, hi = G;   // item_start[lo] <= item < item_start[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (item_start[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int g = lo;
+    const int64_t p0 = start[g] + (int64_t)(item - item_start[g]) * CH;
+    const int64_t p1 = p0 + CH < start[g + 1] ? p0 + CH : start[g + 1];
+    const int nfr = (int)(p1 - p0);
+    const int lane = threadIdx.x, m = lane & 15, kq = lane >> 4, fl = lane & 15;
+    // the state's centre: mean over its components of their means under A, in component order (every rank: same bits)
+    if (lane < H) {
+        double c = 0.0;
+        if (lane < D) {
+            for (int mm = 0; mm < M; mm++) c += meanA[((size_t)g * M + mm) * D + lane];
+            c = c / (double)M;
+        }
+        cs[lane] = c;
+    }
+    __syncthreads();
+    double cen[NV];   // centre of the columns this lane loads
+#pragma unroll
+    for (int kk = 0; kk < NV; kk++) cen[kk] = cs[4 * kk + kq];
+    const double wm = m < M ? (double)weight[(size_t)g * M + m] : 0.0;
+    const double sm = (!LOGP_MFMA && m < M) ? (double)shift_in[(size_t)g * M + m] : 0.0;
+    // W^T as B operand of the first product: lane (k = kq, column m) holds W[m][4 kk + kq] for the 2 NV k-chunks
+    double wreg[LOGP_MFMA ? 2 * NV : 1];
+    if (LOGP_MFMA) {
+        double k0 = 0.0;
+        if (m < M)
+            for (int d = 0; d < D; d++) {
+                const double mu = meanA[((size_t)g * M + m) * D + d] - cs[d];
+                k0 = fma(rvarA[((size_t)g * M + m) * D + d] * mu, mu, k0);
+            }
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) {
+            const int e = 4 * kk + kq;
+            double lin = 0.0, quad = 0.0;
+            if (m < M && e < D) {
+                const double rv = rvarA[((size_t)g * M + m) * D + e];
+                lin = rv * (meanA[((size_t)g * M + m) * D + e] - cs[e]);
+                quad = -0.5 * rv;
+            }
+            if (m < M && e == D) lin = -0.5 * k0;
+            wreg[kk] = lin;
+            wreg[NV + kk] = quad;
+        }
+    }
+    f64x4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; c++) acc[c] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int ntiles = (nfr + 15) >> 4;
+    // frame row of tile t for this lane: frame 16 t + fl, columns 4 kk + kq
+    auto load_ord = [&](int t) -> int {
+        const int f = 16 * t + fl;
+        return f < nfr ? order[p0 + f] : -1;
+    };
+    auto load_row = [&](int o, float (&x)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) {
+            const int e = 4 * kk + kq;
+            x[kk] = (o >= 0 && e < D) ? feats[(int64_t)o * ld + e] : 0.0f;
+        }
+    };
+    int ord_cur = load_ord(0), ord_nxt = ntiles > 1 ? load_ord(1) : -1;
+    float xr[NV];
+    load_row(ord_cur, xr);
+    for (int t = 0; t < ntiles; t++) {
+        // ---- this lane's slice of the tile: centred values (= its A operand of the first product), also into LDS ----
+        double v1[NV];
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) {
+            const int e = 4 * kk + kq;
+            double v = (double)xr[kk] - cen[kk];
+            if (e == D) v = 1.0;
+            if (e > D) v = 0.0;
+            v1[kk] = v;
+            xs[fl][e] = v;
+        }
+        float lpin[4];
+        if (!LOGP_MFMA) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = __shfl(ord_cur, 4 * r + kq, 64);
+                lpin[r] = (o >= 0 && m < M) ? logp_in[(int64_t)o * M + m] : -__builtin_huge_valf();
+            }
+        }
+        __syncthreads();
+        // ---- the next tile's loads fly under this tile's arithmetic ----
+        const int ord_use = ord_nxt;
+        if (t + 1 < ntiles) load_row(ord_use, xr);
+        ord_cur = ord_use;
+        ord_nxt = t + 2 < ntiles ? load_ord(t + 2) : -1;
+        // ---- zeta for frames kq + 4r, component m ----
+        double z[4];
+        if (LOGP_MFMA) {
+            f64x4 L = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) L = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk], wreg[kk], L, 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) L = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk] * v1[kk], wreg[NV + kk], L, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool valid = 16 * t + 4 * r + kq < nfr;
+                // zeta = weight * prob (src/hmm.cpp:282,307,328) relative to the component's peak density
+                z[r] = valid ? wm * srx_exp_f64(L[r]) : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) z[r] = wm * srx_exp_f64((double)lpin[r] - sm);   // -inf past the item's end: 0
+        }
+        // ---- accumulate: A = zeta (component m, frame kq + 4r), B = xx[frame kq + 4r][column group c] ----
+#pragma unroll
+        for (int c = 0; c < NCT; c++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double x = xs[4 * r + kq][8 * c + (fl & 7)];
+                const double b = fl < 8 ? x : x * x;
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[r], b, acc[c], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // the tile is consumed before the next one is written
+    }
+    // C/D of v_mfma_f64_16x16x4_f64: column = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int c = 0; c < NCT; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = kq + 4 * r;
+            const int dim = 8 * c + (fl & 7);
+            const int col = fl < 8 ? dim : H + dim;
+            double v = acc[c][r];
+            if (fl >= 8 && dim == D) v = (double)nfr;   // the spare column: frames of this item
+            if (row < M) partial[((size_t)item * M + row) * K + col] = v;   // columns past D are sums of zeros
+        }
+}
+
+// After the exchange: B from the fused statistics, then gaussian::blend(A, keep) (src/hmm.cpp:288-296, 317, 339-341; src/gmm.cpp:82-88).
+// shift == nullptr: the statistics were taken relative to each component's peak density, recomputed here in f64.  A component
+// that saw frames but whose zeta sum is below 1e-290 has lost them to f64 underflow (every frame tens of standard deviations
+// away): counted in *underflow, and the caller repeats the iteration's statistics through the data-shifted passes.
+__global__ __launch_bounds__(256) void k_em_fused_finish(int G, int M, int D, int H, const double *__restrict__ st,
+                                                         const float *__restrict__ shift, const double *__restrict__ meanA,
+                                                         const double *__restrict__ varA, const float *__restrict__ wA,
+                                                         const float *__restrict__ lwA, double *__restrict__ meanB,
+                                                         double *__restrict__ varB, float *__restrict__ wB, float *__restrict__ lwB, float keep,
+                                                         int32_t *__restrict__ underflow) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)G * M * D) return;
+    const int K = 2 * H;
+    const int e = (int)(idx % D);
+    const size_t o = (size_t)(idx / D);
+    const int g = (int)(o / M);
+    double c = 0.0;
+    for (int mm = 0; mm < M; mm++) c += meanA[((size_t)g * M + mm) * D + e];
+    c = c / (double)M;
+    const double S0 = st[o * K + D], S1 = st[o * K + e], S2 = st[o * K + H + e];
+    const double mu = S1 / S0;
+    double vnew = S2 / S0 - mu * mu;
+    if (vnew < 0.0) vnew = 0.0;   // a component held by one frame: the reference's sum of squared differences is exactly 0
+    const float omk = 1 - keep;
+    meanB[idx] = (c + mu) * (double)keep + meanA[idx] * (double)omk;
+    varB[idx] = vnew * (double)keep + varA[idx] * (double)omk;
+    if (e == 0) {
+        const float l2pi = (float)-0.4515827052894549;
+        auto peak = [&](int mm) -> double {
+            const size_t om = (size_t)g * M + mm;
+            if (shift) return (double)shift[om];
+            double sl = 0.0;
+            for (int d = 0; d < D; d++) sl += (double)l2pi + log(varA[om * D + d]);
+            return (double)lwA[om] - 0.5 * sl;
+        };
+        double pmax = -__builtin_huge_val();
+        for (int mm = 0; mm < M; mm++) {
+            const double p = peak(mm);
+            if (p > pmax) pmax = p;
+        }
+        double zg = 0.0, zo = 0.0;
+        for (int mm = 0; mm < M; mm++) {
+            const size_t om = (size_t)g * M + mm;
+            const double p = peak(mm);
+            const double z = (p == -__builtin_huge_val()) ? 0.0 : st[om * K + D] * exp(p - pmax);
+            zg += z;
+            if (om == o) zo = z;
+        }
+        const float w = (float)(zo / zg);
+        const float a = w * keep;
+        const float b = wA[o] * omk;
+        const float wn = a + b;
+        wB[o] = wn;
+        lwB[o] = logf(wn);
+        if (underflow && st[o * K + H + D] > 0.0 && S0 < 1e-290) atomicAdd(underflow, 1);
+    }
+}
+
 // Log-densities of the aligned frames under A in sorted order: a work item's state parameters sit in LDS and the item's
 // frames stream past them (the frame-order kernel k_em_logp gathers 780 bytes of parameters per (frame, component)
 // through L2).  Same arithmetic as srx_logprob_exact_lc, statement for statement.  A thread owns one component and
@@ -716,6 +947,71 @@ int srx_em_accum_seg(srx_ctx *ctx, const float *feats, int ld, const int32_t *gi
     {
         SrxProf prof_(ctx, "k_em_seg_reduce");
         hipLaunchKernelGGL(k_em_seg_reduce, dim3(G), dim3(256), 0, ctx->stream, v.item_start, G, R, (const double *)pw, stats);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+bool srx_em_fused_applicable(int G, int M, int D) { return M <= 16 && D + 1 <= 8 * FUSED_NCT_MAX && G + 1 <= 16384; }
+int srx_em_fused_row(int D) { return 16 * ((D + 1 + 7) / 8); }   // doubles per (state, component) row of the fused statistics
+
+// logp == nullptr: log-densities on the matrix cores (peak-relative); otherwise the given ones with their shift.
+int srx_em_fused_launch(srx_ctx *ctx, const float *feats, int ld, const int32_t *gid, int64_t T, int G, int M, int D, const double *meanA,
+                        const double *rvarA, const float *weight, const float *logp, const float *shift, double *stats) {
+    const int K = srx_em_fused_row(D);
+    const int R = M * K;
+    SRX_HIP(ctx, hipMemsetAsync(stats, 0, (size_t)G * R * sizeof(double), ctx->stream));
+    if (T == 0) return SRX_OK;
+    // a new alignment under the same pointer is the normal case: only the passes that follow srx_em_shift_dev may reuse its sort
+    if (!logp || ctx->em_gid != gid || ctx->em_T != T || ctx->em_G != G) {
+        int rc = srx_em_seg_sort(ctx, gid, T, G);
+        if (rc != SRX_OK) return rc;
+    }
+    EmSortView v;
+    em_sort_view(ctx->ws[2], T, G, &v);
+    const int64_t max_items = T / CH + G + 1;
+    void *pw = nullptr;
+    int rc = srx_workspace(ctx, 3, (size_t)max_items * R * sizeof(double), &pw);
+    if (rc != SRX_OK) return rc;
+    const int nct = K / 16;
+    {
+        SrxProf prof_(ctx, "k_em_fused");
+#define SRX_FUSED(N)                                                                                                                  \
+    do {                                                                                                                              \
+        if (logp)                                                                                                                     \
+            hipLaunchKernelGGL((k_em_fused<N, false>), dim3((unsigned)max_items), dim3(64), 0, ctx->stream, feats, ld, v.order, v.start, \
+                               v.item_start, G, M, D, meanA, rvarA, weight, logp, shift, (double *)pw);                               \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_em_fused<N, true>), dim3((unsigned)max_items), dim3(64), 0, ctx->stream, feats, ld, v.order, v.start,  \
+                               v.item_start, G, M, D, meanA, rvarA, weight, logp, shift, (double *)pw);                               \
+    } while (0)
+        switch (nct) {
+            case 1: SRX_FUSED(1); break;
+            case 2: SRX_FUSED(2); break;
+            case 3: SRX_FUSED(3); break;
+            case 4: SRX_FUSED(4); break;
+            default: SRX_FUSED(5); break;
+        }
+#undef SRX_FUSED
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    {
+        SrxProf prof_(ctx, "k_em_seg_reduce");
+        hipLaunchKernelGGL(k_em_seg_reduce, dim3(G), dim3(256), 0, ctx->stream, v.item_start, G, R, (const double *)pw, stats);
+    }
+    SRX_LAUNCH_CHECK(ctx);
+    return SRX_OK;
+}
+
+int srx_em_fused_finish_launch(srx_ctx *ctx, int G, int M, int D, const double *stats, const float *shift, const double *meanA,
+                               const double *varA, const float *wA, const float *lwA, double *meanB, double *varB, float *wB, float *lwB,
+                               float keep, int32_t *underflow) {
+    const int64_t n = (int64_t)G * M * D;
+    if (underflow) SRX_HIP(ctx, hipMemsetAsync(underflow, 0, sizeof(int32_t), ctx->stream));
+    {
+        SrxProf prof_(ctx, "k_em_fused_finish");
+        hipLaunchKernelGGL(k_em_fused_finish, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, G, M, D, srx_em_fused_row(D) / 2, stats,
+                           shift, meanA, varA, wA, lwA, meanB, varB, wB, lwB, keep, underflow);
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;

@@ -546,6 +546,33 @@ def em_statistics(ctx, A, B, feats_d, ld, gid_d, T, blend_keep=0.2, allreduce_ma
     return stats1, stats2, shift
 
 
+def em_statistics_fused(ctx, A, B, feats_d, ld, gid_d, T, blend_keep=0.2, given_logp=False, allreduce_max=None, allreduce_sum=None):
+    """The same statistics in one pass on the f64 matrix cores and one exchange (srx_em_fused_dev / srx_em_fused_finish_dev).
+    given_logp: zeta from the rounding-faithful log-densities of srx_em_shift_dev (only the variance pass is folded in);
+    otherwise the log-densities come off the matrix cores too, relative to each component's peak.  Returns
+    (stats12 DevArray, number of components lost to f64 underflow: non-zero asks for the five-step form)."""
+    lib = ctx.lib
+    G, M = A.G, A.M
+    n = int(lib.srx_em_fused_len(A.h))
+    assert n > 0, "shape outside the fused statistics path"
+    stats = ctx.empty((n,), np.float64)
+    under = ctx.zeros((1,), np.int32)
+    logp = shift = None
+    if given_logp:
+        logp = ctx.empty((max(T * M, 1),), np.float32)
+        shift = ctx.empty((G * M,), np.float32)
+        check(lib.srx_em_shift_dev(ctx.h, A.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr, shift.ptr), ctx.h)
+        if allreduce_max:
+            allreduce_max(shift)
+    check(lib.srx_em_fused_dev(ctx.h, A.h, feats_d.ptr, ld, gid_d.ptr, T, logp.ptr if logp else None, shift.ptr if shift else None,
+                               stats.ptr), ctx.h)
+    if allreduce_sum:
+        allreduce_sum(stats)
+    check(lib.srx_em_fused_finish_dev(ctx.h, A.h, B.h, stats.ptr, shift.ptr if shift else None, blend_keep, under.ptr), ctx.h)
+    ctx.sync()
+    return stats, int(under.get()[0])
+
+
 def gather_gid(ctx, hmm, path_d, status_d):
     gid = ctx.empty((max(hmm.total_frames, 1),), np.int32)
     check(ctx.lib.srx_em_gather_gid_dev(ctx.h, C.byref(hmm.c), path_d.ptr, status_d.ptr, hmm.total_frames, gid.ptr), ctx.h)

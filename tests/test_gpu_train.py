@@ -56,6 +56,91 @@ def test_em_statistics_hbm_table(ctx, oracle):
     _run(ctx, oracle, 300, 2, 39, 4000, 4)
 
 
+def _run_fused(ctx, oracle, G, M, D, T, seed, given_logp, far=0.0, offset=0.0):
+    """The one-pass statistics (srx_em_fused_dev) against the long-double oracle.  Returns the worst deviations:
+    (means in units of the component's standard deviation, variances relative, weights relative, underflow count)."""
+    rng = np.random.default_rng(seed)
+    mean, var, w = synth.random_model(G, M, D, seed)
+    mean += offset                         # the whole model (and its data) away from the origin
+    gid = rng.integers(0, G, T).astype(np.int32)
+    gid[gid == 3] = 4                      # tied state 3 is never visited -> NaN row (reference behaviour)
+    feats = np.zeros((T, 39), np.float32)
+    comp = rng.integers(0, M, T)
+    feats[:, :D] = (mean[gid, comp] + rng.standard_normal((T, D)) * np.sqrt(var[gid, comp])).astype(np.float32)
+    feats[:, :D] += far
+    A = host.AcousticModel(ctx, G, M, D)
+    B = host.AcousticModel(ctx, G, M, D)
+    A.set(mean, var, w)
+    B.copy_from(A)
+    _, under = host.em_statistics_fused(ctx, A, B, ctx.array(feats), 39, ctx.array(gid), T, 0.2, given_logp)
+    gm, gv, gw = B.get()
+    rm, rv, rw, rlw, zs = oracle.em_statistics(feats, gid, D, mean, var, w, 0.2)
+    rm, rv = rm.astype(np.float64), rv.astype(np.float64)
+    A.close()
+    B.close()
+    if under:
+        return None, None, None, under
+    assert np.array_equal(np.isnan(gm), np.isnan(rm))
+    assert np.isnan(rm[3]).all() and not np.isnan(rm[4]).any()
+    ok = ~np.isnan(rm)
+    # B = 0.2 new + 0.8 A (gaussian::blend): deviations of the NEW mean / variance are 5x what B shows, and are measured
+    # against the new standard deviation / variance (the oracle's, un-blended)
+    # The variance is formed as S2/S0 - (S1/S0)^2 around the state's centre c: beside the bar on the statistics themselves it
+    # carries the f64 cancellation term 16 * 2^-53 * (vnew + (mean_new - c)^2), which only shows when a component's new mean
+    # is far from c in units of its new spread (a component held by one distant frame); that term is taken out before the
+    # relative deviation is formed.
+    vnew = (rv - 0.8 * var) / 0.2
+    mnew = (rm - 0.8 * mean) / 0.2
+    c = mean.mean(axis=1, keepdims=True)
+    cancel = 16 * 2.0 ** -53 * (vnew + (mnew - c) ** 2)
+    dm = (np.abs(gm - rm)[ok] * 5 / np.sqrt(vnew[ok])).max()
+    dv = (np.maximum(np.abs(gv - rv) * 5 - cancel, 0)[ok] / vnew[ok]).max()
+    okw = ~np.isnan(rw)
+    dw = (np.abs(gw - rw)[okw] / np.maximum(rw[okw], 1e-30)).max() * 5
+    return dm, dv, dw, under
+
+
+@pytest.mark.parametrize("G,M,D,T,seed", [(40, 1, 13, 6000, 1), (12, 4, 13, 5000, 2), (300, 2, 39, 4000, 4), (50, 16, 39, 60000, 5)])
+def test_em_fused_given_logp_folds_only_the_variance_pass(ctx, oracle, G, M, D, T, seed):
+    """zeta from the rounding-faithful log-densities: means and weights are the five-step form's sums (1e-9), the variances
+    come from S2/S0 - (S1/S0)^2 in f64 around the state's centre instead of the reference's sum of f32-rounded differences
+    (src/hmm.cpp:331).  Bar on a new variance: 2^-23 = 1.2e-7 relative -- the reference rounds every difference to f32 (2^-24
+    relative), so every squared term of its sum is off by at most 2^-23 of itself and so is the sum of those non-negative
+    terms; a component with a handful of frames comes close to that bound, one with hundreds averages it down (VERDICT r2
+    measured 7e-9 at 150 frames per state) -- plus the 1e-9 the five-step form is held to.  Means: 1e-9 (in sigmas)."""
+    dm, dv, dw, under = _run_fused(ctx, oracle, G, M, D, T, seed, True)
+    assert under == 0
+    assert dm <= 1e-9 and dv <= 2.0 ** -23 + 1e-9 and dw <= 2e-6, (dm, dv, dw)
+
+
+@pytest.mark.parametrize("G,M,D,T,seed", [(40, 1, 13, 6000, 1), (12, 4, 13, 5000, 2), (300, 2, 39, 4000, 4), (50, 16, 39, 60000, 5)])
+def test_em_fused_matrix_core_log_densities(ctx, oracle, G, M, D, T, seed):
+    """Log-densities on the f64 matrix cores, without the f32 roundings gaussian::operator() applies to every term
+    (src/gmm.cpp:44-47): zeta differs from the reference's by the reference's own rounding noise.  Bar:
+    new means within 1e-5 sigma, new variances within 1e-5 relative after one iteration."""
+    dm, dv, dw, under = _run_fused(ctx, oracle, G, M, D, T, seed, False)
+    assert under == 0
+    assert dm <= 1e-5 and dv <= 1e-5 and dw <= 1e-4, (dm, dv, dw)
+
+
+def test_em_fused_means_far_from_the_origin(ctx, oracle):
+    """Component means hundreds of standard deviations from the origin: S2/S0 - (S1/S0)^2 would cancel without the centring."""
+    dm, dv, dw, under = _run_fused(ctx, oracle, 20, 4, 39, 8000, 7, False, offset=500.0)
+    assert under == 0 and dm <= 1e-5 and dv <= 1e-5, (dm, dv)
+    dm, dv, dw, under = _run_fused(ctx, oracle, 20, 4, 39, 8000, 7, True, offset=500.0)
+    assert under == 0 and dm <= 1e-9 and dv <= 2.0 ** -23 + 1e-9, (dm, dv)
+
+
+def test_em_fused_reports_underflow_instead_of_returning_garbage(ctx, oracle):
+    """Every frame 25 units from every mean: log-densities near -4000 relative to the peak, beyond f64's exp().  The
+    matrix-core form counts the components it lost (the caller then runs the five-step form, which shifts by the data's own
+    maximum: test_em_statistics_underflow_guard); with given log-densities and their shift nothing is lost."""
+    *_, under = _run_fused(ctx, oracle, 10, 2, 13, 3000, 3, False, far=25.0)
+    assert under > 0
+    dm, dv, dw, under = _run_fused(ctx, oracle, 10, 2, 13, 3000, 3, True, far=25.0)
+    assert under == 0 and dm <= 1e-9 and dv <= 2.0 ** -23 + 1e-9, (dm, dv)
+
+
 def test_gather_gid_skips_no_path(ctx):
     ph = np.array([0, 5, 6, 0], np.int32)
     ntr, tr, _ = host.build_training_hmm(ph)
