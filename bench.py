@@ -81,7 +81,18 @@ def cpu_baseline(x, soff, ntrs, trs, tieds, model, budget_s=20.0):
     fb, _ = O.mel_filterbank(FEND, NFILT, WL, SPS)
     mean_l = np.ascontiguousarray(mean, np.longdouble)
     var_l = np.ascontiguousarray(var, np.longdouble)
-    threads = int(min(16, os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    # threads = this job's CPU share: the GPU box exports OMP_NUM_THREADS = 16 for a one-GPU lease while os.cpu_count()
+    # reports every core of the host (SURVEY 8d asks for hardware_concurrency(); a pool that size is not this job's to use)
+    threads = int(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     # calibrate on one short utterance, single thread
     order = np.argsort(np.diff(soff))
     u0 = int(order[0])
@@ -140,6 +151,8 @@ def cpu_baseline(x, soff, ntrs, trs, tieds, model, budget_s=20.0):
                                   f"scoring timed on {nd} frames ({dt_dense:.1f} s, {1.0 / per_frame_dense:.0f} frames/s on {threads} threads) "
                                   "added to the per-frame time of the pipeline above"},
         "value": sum(frames) / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+        "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(), "threads_used": threads,
+        "single_thread": {"value": n0 / dt0, "unit": "frames/s", "what": "the same pipeline on one utterance, one thread (calibration run)"},
         "sample": f"{len(chosen)} shortest of the 1000 utterances ({sum(frames)} frames) in {dt:.1f} s; oracle/srx_oracle.c "
                   f"(naive half-window DFT in f64, long-double Gaussians of the utterance's own states only, "
                   f"accumulating Viterbi); single-thread calibration {n0 / dt0:.0f} frames/s",
@@ -202,8 +215,24 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
     X, Y = (host.AcousticModel(ctx, G, M, D) for _ in range(2))
     X.set(*synth.random_model(G, M, D, 777))
     Y.copy_from(X)
-    ex = parallel.Exchange(force=os.environ.get("SRX_BENCH_FORCE_GROUP", "0") == "1")
-    shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, ex, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3, emissions="compact")
+    # The exchange goes through the library's own communicator (srx_comm_*: ncclAllReduce on the context's stream) -- what
+    # hmm::train / `srx --mode train` of the C++ layer use.  Rank 0 draws the RCCL id, torch.distributed's store hands it round.
+    # SRX_BENCH_BACKEND=gloo (ranks sharing a GPU, which RCCL refuses): the host rehearsal transport of the same communicator.
+    # SRX_BENCH_EXCHANGE=torch selects torch.distributed's all_reduce instead (round 2's form).
+    force = os.environ.get("SRX_BENCH_FORCE_GROUP", "0") == "1"
+    if os.environ.get("SRX_BENCH_EXCHANGE", "srx") == "torch":
+        ex = parallel.Exchange(force=force)
+    elif dist is not None and world > 1 and backend != "nccl":
+        ex = parallel.SrxExchange(ctx, rank, world, shm_name="/srx_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+    else:
+        def broadcast_id(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        ex = parallel.SrxExchange(ctx, rank, world, broadcast_id=broadcast_id, force_rccl=force and world == 1)
+    em_path = os.environ.get("SRX_BENCH_EM_PATH", "fused")
+    shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, ex, SRX_MIX_LOGSUMEXP, SRX_SCORE_MFMA_F16X3, emissions="compact",
+                                   em_path=em_path)
     iters += iters & 1          # whole swap cycles
     warm += warm & 1
     state = {"k": 0}
@@ -247,7 +276,8 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
     kern = {}
     score_ms_per_launch = None
     for k in ("k_gmm_f16_align", "k_viterbi", "k_train_transitions", "k_gather_gid", "k_em_csort_hist", "k_em_csort_scan", "k_em_csort_scatter", "k_em_logp_seg",
-              "k_em_accum_seg1", "k_em_accum_seg2", "k_em_seg_reduce", "k_em_means", "k_em_finish"):
+              "k_em_accum_seg1", "k_em_accum_seg2", "k_em_seg_reduce", "k_em_means", "k_em_finish", "k_em_fused", "k_em_peak",
+              "k_em_fused_finish", "rccl_allreduce_max", "rccl_allreduce_sum"):
         ms, n = ctx.profile_query(k)
         if n:
             kern[k] = ms / iters
@@ -257,8 +287,16 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
     assert (shard.status.get()[:hb.n_utt] == 0).all(), "alignment failed for some utterance"
     (dt_max, dt_all_max), (frames_all, flop_all) = reduce_max_sum(torch, dist, backend, [dt, dt_all], [float(T), flop])
     ms_it = dt_max / iters * 1e3
+    n12 = G * M * 16 * ((D + 1 + 7) // 8)
+    per_iter_bytes = {"faithful": {"max_shift_f32": G * M * 4, "sum_stats1_f64": G * M * (1 + D) * 8, "sum_stats2_f64": G * M * D * 8},
+                      "fold": {"max_shift_f32": G * M * 4, "sum_stats12_f64": n12 * 8},
+                      "fused": {"sum_stats12_f64": n12 * 8}}[em_path]
     out = {"workload": f"configs[4]: one embedded-training iteration over {n_total} utterances split across {world} GPU(s) "
-                       "(alignment-mode scoring + Viterbi + transitions + statistics + 3 all-reduces + blend)",
+                       f"(alignment-mode scoring + Viterbi + transitions + statistics [{em_path}] + {len(per_iter_bytes)} all-reduce(s) + blend)",
+           "statistics_path": em_path, "statistics_fallbacks_to_five_step_form": shard.fallbacks,
+           "exchange": {"through": type(ex).__name__, "transport": ex.transport,
+                        "note": "SrxExchange = srx_comm_* of the C ABI (ncclAllReduce on the context's stream; 'host' = the "
+                                "shared-memory rehearsal for ranks sharing a GPU; 'none' = one rank, every call a no-op)"},
            "scaling": "strong", "utterances_total": n_total, "frames_total": frames_all, "iterations_timed": iters,
            "ms_per_iteration": ms_it, "frames_per_s": frames_all / (ms_it * 1e-3),
            "scoring_passes_per_iteration": shard.scoring_passes / iters,
@@ -268,14 +306,15 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
                    "ms_per_iteration is the mean over whole swap cycles, ..._every_iteration_scored the same loop with the "
                    "reuse switched off",
            "rank0_kernels_ms_per_iteration": kern, "rank0_collectives_ms": coll,
-           "collective_bytes_per_iteration": {"max_shift_f32": G * M * 4, "sum_stats1_f64": G * M * (1 + D) * 8,
-                                              "sum_stats2_f64": G * M * D * 8},
-           "bytes_reduced_per_iteration_counted": ex.bytes_reduced / max(iters, 1),
+           "collective_bytes_per_iteration": per_iter_bytes,
+           "bytes_reduced_per_iteration_counted": ex.counted_bytes() / max(iters, 1),
            "k_gmm_f16_align_ms_per_launch_rank0": score_ms_per_launch,
            "align_scoring_algorithmic_TFLOPs_rank0": (flop / (score_ms_per_launch * 1e-3) / 1e12) if score_ms_per_launch else None}
     hb.close()
     for m_ in (X, Y):
         m_.close()
+    if hasattr(ex, "close"):
+        ex.close()
     return out
 
 

@@ -18,6 +18,7 @@ SRX_MIX_LOGSUMEXP = 1
 SRX_SCORE_MFMA = 0
 SRX_SCORE_EXACT = 1
 SRX_SCORE_MFMA_F16X3 = 2
+SRX_COMM_ID_BYTES = 128
 
 
 class SrxError(RuntimeError):

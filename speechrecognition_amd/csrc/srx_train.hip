@@ -239,6 +239,8 @@ extern "C" int srx_em_shift_dev(srx_ctx *ctx, srx_model *A, const float *feats_d
                            A->G * A->M);
     }
     SRX_LAUNCH_CHECK(ctx);
+    // a new alignment (usually under the same pointer): whatever sort the workspace holds belongs to the previous one
+    ctx->em_gid = nullptr;
     if (T == 0) return SRX_OK;
     // tables beyond LDS: the passes of this alignment run as a segmented reduction over frames sorted by state; the
     // sort belongs to the alignment, and this is the first step every iteration takes with a new one
@@ -333,14 +335,15 @@ bool srx_em_fused_applicable(int G, int M, int D);
 int srx_em_fused_row(int D);
 int srx_em_fused_launch(srx_ctx *ctx, const float *feats, int ld, const int32_t *gid, int64_t T, int G, int M, int D, const double *meanA,
                         const double *rvarA, const float *weight, const float *logp, const float *shift, double *stats);
-int srx_em_fused_finish_launch(srx_ctx *ctx, int G, int M, int D, const double *stats, const float *shift, const double *meanA,
-                               const double *varA, const float *wA, const float *lwA, double *meanB, double *varB, float *wB, float *lwB,
-                               float keep, int32_t *underflow);
+int srx_em_fused_finish_launch(srx_ctx *ctx, int G, int M, int D, const double *stats, const float *shift, const double *lconstA,
+                               double *peak_scratch, const double *meanA, const double *varA, const float *wA, const float *lwA, double *meanB,
+                               double *varB, float *wB, float *lwB, float keep, int32_t *underflow);
 
 static int ensure_lconst(srx_ctx *ctx, srx_model *A) {
     if (A->lconst_version != A->version || !A->lconst) {
         const int64_t nl = (int64_t)A->G * A->M * A->D;
-        if (!A->lconst) SRX_HIP(ctx, hipMalloc((void **)&A->lconst, (size_t)2 * nl * sizeof(double)));
+        // [G*M*D] lconst, [G*M*D] 1/var, then [G*M] scratch for the components' peak log-densities (srx_em_fused_finish_dev)
+        if (!A->lconst) SRX_HIP(ctx, hipMalloc((void **)&A->lconst, ((size_t)2 * nl + (size_t)A->G * A->M) * sizeof(double)));
         {
             SrxProf prof_(ctx, "k_model_lconst");
             hipLaunchKernelGGL(k_model_lconst, dim3((unsigned)ceil_div64(nl, 256)), dim3(256), 0, ctx->stream, A->var, nl, A->lconst);
@@ -376,8 +379,11 @@ extern "C" int srx_em_fused_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B,
     SRX_REQUIRE(ctx, A && B && stats12_dev, "srx_em_fused_finish_dev: null argument");
     SRX_REQUIRE(ctx, A->G == B->G && A->M == B->M && A->D == B->D, "srx_em_fused_finish_dev: model shape mismatch");
     SRX_REQUIRE(ctx, srx_em_fused_applicable(A->G, A->M, A->D), "srx_em_fused_finish_dev: shape outside the fused path");
-    int rc = srx_em_fused_finish_launch(ctx, A->G, A->M, A->D, stats12_dev, shift_dev, A->mean, A->var, A->weight, A->logwt, B->mean, B->var,
-                                        B->weight, B->logwt, blend_keep, underflow_dev);
+    int rc = ensure_lconst(ctx, A);
+    if (rc != SRX_OK) return rc;
+    const size_t nl = (size_t)A->G * A->M * A->D;
+    rc = srx_em_fused_finish_launch(ctx, A->G, A->M, A->D, stats12_dev, shift_dev, A->lconst, A->lconst + 2 * nl, A->mean, A->var, A->weight,
+                                    A->logwt, B->mean, B->var, B->weight, B->logwt, blend_keep, underflow_dev);
     if (rc != SRX_OK) return rc;
     B->version++;
     return SRX_OK;

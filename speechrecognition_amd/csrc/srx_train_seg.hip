@@ -499,8 +499,11 @@ __global__ __launch_bounds__(64) void k_em_accum1_mfma(const float *__restrict__
 // underflow test of k_em_fused_finish).
 static constexpr int FUSED_NCT_MAX = 5;   // D + 1 <= 8 * NCT: D <= 39
 
+#ifndef SRX_FUSED_WPE
+#define SRX_FUSED_WPE 2   // waves per SIMD the kernel is compiled for
+#endif
 template <int NCT, bool LOGP_MFMA>
-__global__ __launch_bounds__(64, 2) void k_em_fused(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__restrict__ feats, int ld, const int32_t *__restrict__ order,
                                                     const int64_t *__restrict__ start, const int32_t *__restrict__ item_start, int G, int M,
                                                     int D, const double *__restrict__ meanA, const double *__restrict__ rvarA,
                                                     const float *__restrict__ weight, const float *__restrict__ logp_in,
@@ -606,16 +609,18 @@ __global__ __launch_bounds__(64, 2) void k_em_fused(const float *__restrict__ fe
         // ---- zeta for frames kq + 4r, component m ----
         double z[4];
         if (LOGP_MFMA) {
-            f64x4 L = (f64x4){0.0, 0.0, 0.0, 0.0};
+            // two independent accumulation chains (linear and quadratic columns) so that consecutive MFMAs do not wait on each other
+            f64x4 L = (f64x4){0.0, 0.0, 0.0, 0.0}, Q = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kk = 0; kk < NV; kk++) L = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk], wreg[kk], L, 0, 0, 0);
-#pragma unroll
-            for (int kk = 0; kk < NV; kk++) L = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk] * v1[kk], wreg[NV + kk], L, 0, 0, 0);
+            for (int kk = 0; kk < NV; kk++) {
+                L = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk], wreg[kk], L, 0, 0, 0);
+                Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk] * v1[kk], wreg[NV + kk], Q, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const bool valid = 16 * t + 4 * r + kq < nfr;
                 // zeta = weight * prob (src/hmm.cpp:282,307,328) relative to the component's peak density
-                z[r] = valid ? wm * srx_exp_f64(L[r]) : 0.0;
+                z[r] = valid ? wm * srx_exp_f64(L[r] + Q[r]) : 0.0;
             }
         } else {
 #pragma unroll
@@ -647,12 +652,22 @@ __global__ __launch_bounds__(64, 2) void k_em_fused(const float *__restrict__ fe
         }
 }
 
+// peak[o] = logp_o(mean_o) = logwt_o - 1/2 sum_d (log(2/pi) + log var_od): what the matrix-core log-densities are relative to
+__global__ __launch_bounds__(256) void k_em_peak(int GM, int D, const double *__restrict__ lconst, const float *__restrict__ lw,
+                                                 double *__restrict__ peak) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= GM) return;
+    double sl = 0.0;
+    for (int d = 0; d < D; d++) sl += lconst[(size_t)o * D + d];
+    peak[o] = (double)lw[o] - 0.5 * sl;
+}
+
 // After the exchange: B from the fused statistics, then gaussian::blend(A, keep) (src/hmm.cpp:288-296, 317, 339-341; src/gmm.cpp:82-88).
 // shift == nullptr: the statistics were taken relative to each component's peak density, recomputed here in f64.  A component
 // that saw frames but whose zeta sum is below 1e-290 has lost them to f64 underflow (every frame tens of standard deviations
 // away): counted in *underflow, and the caller repeats the iteration's statistics through the data-shifted passes.
 __global__ __launch_bounds__(256) void k_em_fused_finish(int G, int M, int D, int H, const double *__restrict__ st,
-                                                         const float *__restrict__ shift, const double *__restrict__ meanA,
+                                                         const float *__restrict__ shift, const double *__restrict__ peakA, const double *__restrict__ meanA,
                                                          const double *__restrict__ varA, const float *__restrict__ wA,
                                                          const float *__restrict__ lwA, double *__restrict__ meanB,
                                                          double *__restrict__ varB, float *__restrict__ wB, float *__restrict__ lwB, float keep,
@@ -674,13 +689,9 @@ __global__ __launch_bounds__(256) void k_em_fused_finish(int G, int M, int D, in
     meanB[idx] = (c + mu) * (double)keep + meanA[idx] * (double)omk;
     varB[idx] = vnew * (double)keep + varA[idx] * (double)omk;
     if (e == 0) {
-        const float l2pi = (float)-0.4515827052894549;
         auto peak = [&](int mm) -> double {
             const size_t om = (size_t)g * M + mm;
-            if (shift) return (double)shift[om];
-            double sl = 0.0;
-            for (int d = 0; d < D; d++) sl += (double)l2pi + log(varA[om * D + d]);
-            return (double)lwA[om] - 0.5 * sl;
+            return shift ? (double)shift[om] : peakA[om];
         };
         double pmax = -__builtin_huge_val();
         for (int mm = 0; mm < M; mm++) {
@@ -1003,15 +1014,20 @@ int srx_em_fused_launch(srx_ctx *ctx, const float *feats, int ld, const int32_t 
     return SRX_OK;
 }
 
-int srx_em_fused_finish_launch(srx_ctx *ctx, int G, int M, int D, const double *stats, const float *shift, const double *meanA,
-                               const double *varA, const float *wA, const float *lwA, double *meanB, double *varB, float *wB, float *lwB,
-                               float keep, int32_t *underflow) {
+int srx_em_fused_finish_launch(srx_ctx *ctx, int G, int M, int D, const double *stats, const float *shift, const double *lconstA,
+                               double *peak_scratch, const double *meanA, const double *varA, const float *wA, const float *lwA, double *meanB,
+                               double *varB, float *wB, float *lwB, float keep, int32_t *underflow) {
     const int64_t n = (int64_t)G * M * D;
     if (underflow) SRX_HIP(ctx, hipMemsetAsync(underflow, 0, sizeof(int32_t), ctx->stream));
+    if (!shift) {
+        SrxProf prof_(ctx, "k_em_peak");
+        hipLaunchKernelGGL(k_em_peak, dim3((G * M + 255) / 256), dim3(256), 0, ctx->stream, G * M, D, lconstA, lwA, peak_scratch);
+    }
+    SRX_LAUNCH_CHECK(ctx);
     {
         SrxProf prof_(ctx, "k_em_fused_finish");
         hipLaunchKernelGGL(k_em_fused_finish, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream, G, M, D, srx_em_fused_row(D) / 2, stats,
-                           shift, meanA, varA, wA, lwA, meanB, varB, wB, lwB, keep, underflow);
+                           shift, peak_scratch, meanA, varA, wA, lwA, meanB, varB, wB, lwB, keep, underflow);
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;

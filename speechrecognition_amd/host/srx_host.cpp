@@ -86,6 +86,17 @@ int env_choice(const char *name, const char *alt, int dflt, int other) {
     const char *v = std::getenv(name);
     return (v && !std::strcmp(v, alt)) ? other : dflt;
 }
+// How hmm::train takes its statistics (include/srx.h, srx_em_fused_dev): SRX_EM_PATH=faithful -- the five steps that reproduce
+// every f32 rounding of the reference, three exchanges; fold -- the same log-densities, variance pass folded into the first
+// (one MAX + one SUM); default (fused) -- log-densities on the f64 matrix cores as well, one SUM, with the five-step form as
+// the fallback for an iteration that loses a component to f64 underflow.
+int em_path_choice() {
+    const char *v = std::getenv("SRX_EM_PATH");
+    if (v && !std::strcmp(v, "faithful")) return 0;
+    if (v && !std::strcmp(v, "fold")) return 1;
+    return 2;
+}
+int g_em_path = em_path_choice();
 int g_mix_mode = env_choice("SRX_MIX", "logsumexp", SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP);
 int g_score_path = env_choice("SRX_SCORE_PATH", "f16x3", env_choice("SRX_SCORE_PATH", "exact", SRX_SCORE_MFMA, SRX_SCORE_EXACT),
                               SRX_SCORE_MFMA_F16X3);
@@ -1343,6 +1354,10 @@ void hmm::train(vector<utterance> &ut, int iterations) {
     Dev<float> d_e(n_emis ? n_emis : 1), d_final((size_t)b.c.n_utt), d_logp((size_t)T * M), d_shift((size_t)G * M);
     Dev<int32_t> d_path((size_t)T), d_status((size_t)b.c.n_utt), d_gid((size_t)T);
     Dev<double> d_s1((size_t)G * M * (1 + FV_LEN)), d_s2((size_t)G * M * FV_LEN);
+    // the one-pass statistics where the shape allows (M <= 16, D <= 39, G <= 16383: srx_em_fused_len is 0 otherwise)
+    const int64_t n12 = g_em_path != 0 ? srx_em_fused_len(acm->device()) : 0;
+    Dev<double> d_s12((size_t)(n12 > 0 ? n12 : 1));
+    Dev<int32_t> d_under(1);
     vector<float> prevp(ut.size(), 0.0f);
     uint64_t scored_version = 0;   // version of the utterances' model that d_e was scored under (0: never)
     for (int it = 1; it <= iterations; it++) {
@@ -1387,14 +1402,36 @@ void hmm::train(vector<utterance> &ut, int iterations) {
         // `ut` is this rank's shard of the corpus: the sums of the reference's three sequential loops over ALL utterances
         // (src/hmm.cpp:275, 298, 319) are completed across the ranks at the three points below (world 1: no-ops); every
         // rank then rebuilds the identical temp_acm
-        check(srx_em_shift_dev(ctx, A, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p));
-        check(srx_allreduce_max_f32_dev(comm, d_shift.p, (int64_t)G * M));
-        check(srx_em_pass1_dev(ctx, A, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p, d_s1.p));
-        check(srx_allreduce_sum_f64_dev(comm, d_s1.p, (int64_t)G * M * (1 + FV_LEN)));
-        check(srx_em_means_dev(ctx, B, d_s1.p, d_shift.p));
-        check(srx_em_pass2_dev(ctx, A, B, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p, d_s2.p));
-        check(srx_allreduce_sum_f64_dev(comm, d_s2.p, (int64_t)G * M * FV_LEN));
-        check(srx_em_finish_dev(ctx, A, B, d_s1.p, d_s2.p, GMM_BLEND_FAC));
+        bool done = false;
+        if (n12 > 0) {
+            const bool given = g_em_path == 1;
+            if (given) {
+                check(srx_em_shift_dev(ctx, A, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p));
+                check(srx_allreduce_max_f32_dev(comm, d_shift.p, (int64_t)G * M));
+            }
+            check(srx_em_fused_dev(ctx, A, d_x.p, ld, d_gid.p, T, given ? d_logp.p : nullptr, given ? d_shift.p : nullptr, d_s12.p));
+            check(srx_allreduce_sum_f64_dev(comm, d_s12.p, n12));
+            check(srx_em_fused_finish_dev(ctx, A, B, d_s12.p, given ? d_shift.p : nullptr, GMM_BLEND_FAC, given ? nullptr : d_under.p));
+            done = given;
+            if (!given) {
+                // formed from the SUMMED statistics: every rank reads the same count and takes the same branch
+                int32_t lost = 0;
+                d_under.download(&lost, 1);
+                done = lost == 0;
+                if (!done && srx::verbose())
+                    std::cout << lost << " components lost to f64 underflow: this iteration through the data-shifted passes" << std::endl;
+            }
+        }
+        if (!done) {
+            check(srx_em_shift_dev(ctx, A, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p));
+            check(srx_allreduce_max_f32_dev(comm, d_shift.p, (int64_t)G * M));
+            check(srx_em_pass1_dev(ctx, A, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p, d_s1.p));
+            check(srx_allreduce_sum_f64_dev(comm, d_s1.p, (int64_t)G * M * (1 + FV_LEN)));
+            check(srx_em_means_dev(ctx, B, d_s1.p, d_shift.p));
+            check(srx_em_pass2_dev(ctx, A, B, d_x.p, ld, d_gid.p, T, d_logp.p, d_shift.p, d_s2.p));
+            check(srx_allreduce_sum_f64_dev(comm, d_s2.p, (int64_t)G * M * FV_LEN));
+            check(srx_em_finish_dev(ctx, A, B, d_s1.p, d_s2.p, GMM_BLEND_FAC));
+        }
         // swap references (src/hmm.cpp:344-346)
         acoustic_model *t = acm;
         acm = temp_acm;

@@ -23,6 +23,10 @@ def logp_f64(x, mean, var, lw):
     return -0.5 * (math.log(2 / math.pi) + np.log(var) + (x[:, None, :] - mean) ** 2 / var).sum(-1) + lw
 
 
+def z_files(work):
+    return np.load(os.path.join(work, "in.npz")).files
+
+
 def main():
     mode, work = sys.argv[1], sys.argv[2]
     import torch
@@ -39,8 +43,14 @@ def main():
     z = np.load(os.path.join(work, "in.npz"))
     G, M, D = [int(v) for v in z["shape"]]
     mean, var, w = z["mean"], z["var"], z["w"]
-    ex = parallel.Exchange(force=rccl)   # a one-rank RCCL group still runs its all-reduces
-    assert ex.active == (world > 1 or rccl)
+    # "exchange": "torch" (default: torch.distributed all_reduce) or "srx" -- the library's own communicator (srx_comm_*: what
+    # hmm::train of the C++ layer uses): RCCL with one forced rank under gpu_rccl, the host rehearsal transport for ranks that
+    # share the GPU
+    use_srx = "exchange" in z_files(work) and str(np.load(os.path.join(work, "in.npz"))["exchange"]) == "srx"
+    ex = None
+    if not use_srx:
+        ex = parallel.Exchange(force=rccl)   # a one-rank RCCL group still runs its all-reduces
+        assert ex.active == (world > 1 or rccl)
     if mode == "cpu":
         feats, gid, frame_off = z["feats"], z["gid"], z["frame_off"]
         costs = np.diff(frame_off)
@@ -82,6 +92,13 @@ def main():
     else:
         from speechrecognition_amd import host
         ctx = host.Context(0)
+        if use_srx:
+            if rccl:
+                ex = parallel.SrxExchange(ctx, 0, 1, force_rccl=True)
+                assert ex.transport == "rccl"
+            else:
+                ex = parallel.SrxExchange(ctx, rank, world, shm_name="/srx_test_%s" % os.environ["MASTER_PORT"])
+                assert ex.transport == ("host" if world > 1 else "none")
         feats, frame_off = z["feats"], z["frame_off"]
         n_utt = len(frame_off) - 1
         phones = [z["ph%d" % u] for u in range(n_utt)]
@@ -97,7 +114,8 @@ def main():
         Cm.copy_from(O)
         shard = parallel.TrainingShard(ctx, hb, ctx.array(x) if len(x) else ctx.zeros((1, feats.shape[1]), np.float32),
                                        feats.shape[1], G, M, D, ex, int(z["mix_mode"]), 1,
-                                       emissions=str(z["emissions"]) if "emissions" in z.files else "dense")
+                                       emissions=str(z["emissions"]) if "emissions" in z.files else "dense",
+                                       em_path=str(z["em_path"]) if "em_path" in z.files else "faithful")
         A, B = O, Cm
         for _ in range(int(z["iters"])):
             shard.iteration(O, A, B, 0.2)     # Viterbi always under O
@@ -105,7 +123,9 @@ def main():
         ctx.sync()
         m_, v_, w_ = A.get()
         np.savez(os.path.join(work, "out%d.npz" % rank), mean=m_, var=v_, w=w_, trlogp=hb.trlogp(), mine=mine,
-                 path=shard.path.get()[:hb.total_frames], bytes_reduced=ex.bytes_reduced)
+                 path=shard.path.get()[:hb.total_frames], bytes_reduced=ex.bytes_reduced, fallbacks=shard.fallbacks)
+        if use_srx:
+            ex.close()
         ctx.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -250,7 +250,9 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
             f.write("state 0 %d 0\nw 1\nmean %s\nvar %s\n" % (g, " ".join(repr(float(v)) for v in mean0[g, 0]),
                                                            " ".join(repr(float(v)) for v in var0[g, 0])))
     iters = 3
-    env = {"SRX_SCORE_PATH": "exact"}
+    # SRX_EM_PATH=faithful: the five statistics steps that reproduce every f32 rounding of the reference (tight bars below);
+    # the driver's default, the one-pass statistics on the f64 matrix cores, is compared further down at its own bars
+    env = {"SRX_SCORE_PATH": "exact", "SRX_EM_PATH": "faithful"}
     _run([SRX, "--mode", "train", "--voxforge", root, "--iters", str(iters), "--model", root + "init.txt", "--out",
           root + "trained.txt"], env)
     # ---- the same three iterations with the oracle, including the acm / temp_acm ping-pong:
@@ -282,6 +284,20 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
     assert ok.sum() > 13 * 10
     np.testing.assert_allclose(gm[ok], rm[ok], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(gv[ok], rv[ok], rtol=1e-7, atol=1e-9)
+    # ---- the default statistics path of hmm::train (srx_em_fused_dev: log-densities and sums on the f64 matrix cores, one
+    # exchange) and the variance-fold-only form: three iterations against the same oracle.  Bars: means
+    # within 1e-4 sigma and variances within 1e-4 relative after three iterations for the former; 1e-6 for the latter.
+    for em_path, bar in (("fused", 1e-4), ("fold", 1e-6)):
+        fn = root + "trained_%s.txt" % em_path
+        _run([SRX, "--mode", "train", "--voxforge", root, "--iters", str(iters), "--model", root + "init.txt", "--out", fn],
+             {"SRX_SCORE_PATH": "exact", "SRX_EM_PATH": em_path})
+        txt = open(fn).read().split("\n")
+        fm = np.array([[float(v) for v in ln.split()[1:]] for ln in txt if ln.startswith("mean")])
+        fv_ = np.array([[float(v) for v in ln.split()[1:]] for ln in txt if ln.startswith("var")])
+        assert np.array_equal(np.isnan(fm), np.isnan(rm))
+        dm = (np.abs(fm - rm)[ok] / np.sqrt(rv[ok])).max()
+        dv = (np.abs(fv_ - rv)[ok] / rv[ok]).max()
+        assert dm <= bar and dv <= bar, (em_path, dm, dv)
     # mean/variance initialisation path (src/main.cpp:52-54; random jitter, so only that it runs and writes a model)
     _run([SRX, "--mode", "train", "--voxforge", root, "--iters", "1", "--out", root + "rand.txt"], env)
     assert open(root + "rand.txt").readline().split() == ["srx-model", "40", "1", "13"]

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--utts", type=int, default=10000)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--em-path", default="faithful,fold,fused", help="statistics paths to time (comma separated)")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -81,22 +82,27 @@ def main():
         out["emis_dense_GB"] = G * T * 4 / 1e9
         del emis
     ctx.profile_enable(False)
-    shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, mix_mode=SRX_MIX_LOGSUMEXP, score_path=SRX_SCORE_MFMA_F16X3,
-                                   emissions="compact")
-    shard.reuse_scores = False   # one model object, never rewritten here: time the iteration WITH its scoring pass
-    shard.iteration(A, A, B, 0.2)   # first launches load their code objects: keep that out of the event pairs
-    ctx.sync()
-    ctx.profile_enable(True)
-    out["training_iteration_ms"] = timed(lambda: shard.iteration(A, A, B, 0.2))
-    kern = {}
-    for k in ("k_gmm_f16_align", "k_viterbi", "k_train_transitions", "k_gather_gid", "k_fill_f32", "k_em_logp", "k_em_accum1",
-              "k_em_means", "k_em_accum2", "k_em_finish", "k_em_csort_hist", "k_em_csort_scan", "k_em_csort_scatter",
-              "k_em_item_scan", "k_em_logp_seg", "k_em_logp_skipped", "k_em_accum_seg1", "k_em_accum_seg2", "k_em_seg_reduce"):
-        ms, n = ctx.profile_query(k)
-        if n:
-            kern[k] = ms / n
-    out["training_kernels_ms"] = kern
-    out["training_frames_per_s"] = T / (out["training_iteration_ms"] * 1e-3)
+    for em_path in args.em_path.split(","):
+        shard = parallel.TrainingShard(ctx, hb, feats_d, D, G, M, D, mix_mode=SRX_MIX_LOGSUMEXP, score_path=SRX_SCORE_MFMA_F16X3,
+                                       emissions="compact", em_path=em_path)
+        shard.reuse_scores = False   # one model object, never rewritten here: time the iteration WITH its scoring pass
+        shard.iteration(A, A, B, 0.2)   # first launches load their code objects: keep that out of the event pairs
+        ctx.sync()
+        ctx.profile_enable(True)
+        ms_it = timed(lambda: shard.iteration(A, A, B, 0.2))
+        kern = {}
+        for k in ("k_gmm_f16_align", "k_viterbi", "k_train_transitions", "k_gather_gid", "k_fill_f32", "k_em_logp", "k_em_accum1",
+                  "k_em_means", "k_em_accum2", "k_em_finish", "k_em_csort_hist", "k_em_csort_scan", "k_em_csort_scatter",
+                  "k_em_item_scan", "k_em_logp_seg", "k_em_logp_skipped", "k_em_accum_seg1", "k_em_accum_seg2", "k_em_seg_reduce",
+                  "k_em_fused", "k_em_fused_finish", "k_model_lconst"):
+            ms, n = ctx.profile_query(k)
+            if n:
+                kern[k] = ms / (args.reps + 1)     # per iteration (timed() runs one untimed pass first)
+        ctx.profile_enable(False)
+        out["training_" + em_path] = {"iteration_ms": ms_it, "frames_per_s": T / (ms_it * 1e-3), "kernels_ms_per_iteration": kern,
+                                       "statistics_ms": sum(v for k, v in kern.items() if k.startswith(("k_em_", "k_fill", "k_model_lconst"))),
+                                       "fallbacks": shard.fallbacks}
+        del shard
     out["alignment_frames_per_s"] = T / (out["align_mode_ms"] * 1e-3)
     print(json.dumps(out))
 
