@@ -370,6 +370,13 @@ def main():
                     help="GMM scoring kernel: split-f16 MFMA (default) or f32-input MFMA")
     args = ap.parse_args()
 
+    # Rank 0's stdout carries ONE JSON line and nothing else: libraries that greet on stdout (RCCL prints a version banner when
+    # a communicator is created outside torch) are sent to stderr for the whole run, and the line goes out through the saved
+    # descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -553,7 +560,9 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(x, soff, ntrs, trs, tieds, model_np)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
