@@ -107,7 +107,10 @@ int srx_mfcc_plan_bin_max(const srx_mfcc_plan *plan);
  * SRX_MFCC_F16X3: operands split into two f16 parts, three products on the f16 matrix cores (half windows of 160
  * or 200 samples, i.e. the reference's 320 and BASELINE's 400-sample windows); SRX_MFCC_F32: f32 matrix cores, any
  * window; SRX_MFCC_AUTO (default): F16X3 where it applies.  No counterpart in the reference (a tuning knob). */
-enum { SRX_MFCC_AUTO = 0, SRX_MFCC_F32 = 1, SRX_MFCC_F16X3 = 2 };
+enum { SRX_MFCC_AUTO = 0, SRX_MFCC_F32 = 1, SRX_MFCC_F16X3 = 2,
+       SRX_MFCC_FFT = 3 /* the half-window transform as ONE packed real FFT of N/2 points in LDS (N/2 = 8*5*5, 8*5*4,
+                           8*4*4, 8*8*4: windows of 400, 320, 256, 512 samples), f32 vector arithmetic, no matrix cores.
+                           Measured 1.7-1.9x slower than F16X3 (profiles/r03_mfcc_fft_vs_dense.json): never picked by AUTO */ };
 int srx_mfcc_plan_set_path(srx_mfcc_plan *plan, int path);
 
 /* Frame count of the do/while(window.slide()) loop, src/mfcc.cpp:261-271 + src/clip.cpp:108-112:

@@ -20,9 +20,10 @@ struct srx_ctx {
     int num_cus = 256;
     char err[512] = {0};
     // grow-only device workspace (Viterbi back-pointer words, ...)
-    // slot 0: GMM operand rows, 1: Viterbi back-pointers, 2: frames sorted by state (EM statistics), 3: EM partial sums
-    void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t ws_bytes[4] = {0, 0, 0, 0};
+    // slot 0: GMM operand rows, 1: Viterbi back-pointers, 2: frames sorted by state (EM statistics), 3: EM partial sums,
+    // 4: utterance of each frame block (FFT path of the MFCC)
+    void *ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[5] = {0, 0, 0, 0, 0};
     // what slot 2 currently holds (srx_train_seg.hip): the alignment it was sorted from
     const int32_t *em_gid = nullptr;
     int64_t em_T = -1;

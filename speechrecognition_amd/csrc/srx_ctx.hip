@@ -45,7 +45,7 @@ extern "C" void srx_ctx_destroy(srx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 5; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     for (auto &r : ctx->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto &t : ctx->tables) (void)hipFree(t.dev);

@@ -381,13 +381,23 @@ extern "C" int srx_mfcc_plan_create(srx_ctx *ctx, const srx_mfcc_cfg *cfg, const
             return rc;
         }
     }
+    if (srx_mfccfft_supported(N, n_filters, cfg->n_ceps)) {
+        int rc = srx_mfccfft_build(p, fb);
+        if (rc != SRX_OK) {
+            srx_mfcc_plan_destroy(p);
+            return rc;
+        }
+    }
     *out = p;
     return SRX_OK;
 }
 
 extern "C" int srx_mfcc_plan_set_path(srx_mfcc_plan *p, int path) {
     if (!p) return SRX_ERR_INVALID;
-    SRX_REQUIRE(p->ctx, path == SRX_MFCC_AUTO || path == SRX_MFCC_F32 || path == SRX_MFCC_F16X3, "srx_mfcc_plan_set_path: unknown path %d", path);
+    SRX_REQUIRE(p->ctx, path == SRX_MFCC_AUTO || path == SRX_MFCC_F32 || path == SRX_MFCC_F16X3 || path == SRX_MFCC_FFT,
+                "srx_mfcc_plan_set_path: unknown path %d", path);
+    SRX_REQUIRE(p->ctx, path != SRX_MFCC_FFT || p->fft_tw,
+                "srx_mfcc_plan_set_path: the FFT path covers windows of 256, 320, 400 and 512 samples (half window 8*4*4, 8*5*4, 8*5*5, 8*8*4)");
     SRX_REQUIRE(p->ctx, path != SRX_MFCC_F16X3 || p->ks16 > 0,
                 "srx_mfcc_plan_set_path: the split-f16 path covers half windows of 145..160 or 193..208 samples, <= 64 filters, <= 256 bins");
     p->path = path;
@@ -396,6 +406,9 @@ extern "C" int srx_mfcc_plan_set_path(srx_mfcc_plan *p, int path) {
 
 extern "C" void srx_mfcc_plan_destroy(srx_mfcc_plan *p) {
     if (!p) return;
+    (void)hipFree(p->fft_tw);
+    (void)hipFree(p->fft_fbw);
+    (void)hipFree(p->fft_fblo);
     (void)hipFree(p->pk16);
     (void)hipFree(p->dct16);
     (void)hipFree(p->win);
@@ -428,6 +441,9 @@ static int mfcc_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *sam
         }
         SRX_LAUNCH_CHECK(ctx);
     }
+    if (!spec_dev && plan->path == SRX_MFCC_FFT)
+        return srx_mfccfft_launch(ctx, plan, samples_dev, sample_off_dev, n_utt, frame_off_dev, total_frames,
+                                  c.normalize ? scratch_scale_dev : nullptr, ceps_dev);
     if (!spec_dev && plan->ks16 > 0 && plan->path != SRX_MFCC_F32)
         return srx_mfcc16_launch(ctx, plan, samples_dev, sample_off_dev, n_utt, frame_off_dev, total_frames,
                                  c.normalize ? scratch_scale_dev : nullptr, ceps_dev);

@@ -22,6 +22,12 @@ struct srx_mfcc_plan {
     int nbt16 = 0;          // 32-bin tiles
     void *pk16 = nullptr;     // [nbt16] chunks of MFMA fragments: twiddles then filterbank columns of the tile
     void *dct16 = nullptr;    // DCT fragments
+    // LDS FFT path (srx_mfcc_fft.hip); fft_tw == nullptr: not available for this window
+    void *fft_tw = nullptr;     // float2 twiddles: [R0*R1] stage 2, [H] stage 3, [H+1] unpacking of the real transform
+    float *fft_fbw = nullptr;   // [fft_fbt] filter taps over each filter's own bins, filter after filter
+    int *fft_fblo = nullptr;    // [nfilt] first bin, [nfilt] number of bins, [nfilt] offset of the taps
+    int fft_fbt = 0;            // taps of all filters together
+    int fft_r[3] = {0, 0, 0};
 };
 
 // srx_mfcc_f16.hip
@@ -30,3 +36,9 @@ int srx_mfcc16_build(srx_mfcc_plan *p, const std::vector<float> &win, const std:
                      const std::vector<float> &dm);
 int srx_mfcc16_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev, const int64_t *sample_off_dev, int n_utt,
                       const int64_t *frame_off_dev, int64_t total_frames, const float *scale_dev, float *ceps_dev);
+
+// srx_mfcc_fft.hip
+bool srx_mfccfft_supported(int window_len, int n_filters, int n_ceps);
+int srx_mfccfft_build(srx_mfcc_plan *p, const srx_filter *fb);
+int srx_mfccfft_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samples_dev, const int64_t *sample_off_dev, int n_utt,
+                       const int64_t *frame_off_dev, int64_t total_frames, const float *scale_dev, float *ceps_dev);

@@ -144,7 +144,7 @@ def frame_offsets(cfg, sample_off):
     return fo
 
 
-MFCC_AUTO, MFCC_F32, MFCC_F16X3 = 0, 1, 2
+MFCC_AUTO, MFCC_F32, MFCC_F16X3, MFCC_FFT = 0, 1, 2, 3
 
 
 class MfccPlan:

@@ -27,7 +27,7 @@ def _oracle_batch(O, x, off, wl, hop, fb, nparams=13, normalize=True):
     return np.concatenate(outs)
 
 
-PATHS = [host.MFCC_F16X3, host.MFCC_F32]
+PATHS = [host.MFCC_F16X3, host.MFCC_F32, host.MFCC_FFT]
 
 
 @pytest.mark.parametrize("path", PATHS)
@@ -134,6 +134,28 @@ def test_mirrored_bins_near_nyquist(ctx, oracle):
     ref = _oracle_batch(oracle, x, off, wl, hop, fb)
     assert _frame_rel_err(ceps, ref) <= 1e-4
     plan.close()
+
+
+@pytest.mark.parametrize("wl,hop,nf,sps", [(256, 128, 24, 12000), (512, 160, 40, 16000), (256, 100, 20, 8000)])
+def test_fft_path_other_windows_and_mirrored_bins(ctx, oracle, wl, hop, nf, sps):
+    """The LDS FFT path on its other radix plans (half window 128 = 8*4*4, 256 = 8*8*4) and, at 12 kHz, with the top filter
+    beyond N/2: the mirrored bins of src/clip.cpp:186-192 are an index map on the FFT's magnitudes."""
+    fb, bm = host.mel_filterbank(0.45 * sps if sps != 12000 else 7200, nf, wl, sps)
+    if sps == 12000:
+        assert bm > wl // 2
+    lens = [3000, wl + 1, 2 * wl + 7]
+    off = np.zeros(len(lens) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    x = np.concatenate([synth.utterance_audio(40 + i, n) for i, n in enumerate(lens)])
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop), fb, host.MFCC_FFT)
+    ceps, _ = plan.write_features(x, off)
+    ref = _oracle_batch(oracle, x, off, wl, hop, fb)
+    assert ceps.shape == ref.shape and _frame_rel_err(ceps, ref) <= 1e-4
+    plan.close()
+    small = host.MfccPlan(ctx, host.mfcc_config(64, 32), host.mel_filterbank(7200, 6, 64, 12000)[0])
+    with pytest.raises(Exception):
+        small.set_path(host.MFCC_FFT)          # a 32-sample half window has no radix plan
+    small.close()
 
 
 def test_normalize_and_preemphasis_in_place_ops(ctx, oracle):
