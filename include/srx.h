@@ -357,6 +357,16 @@ int srx_decode_plan_create(srx_ctx *ctx, int n_states, const int32_t *tr_off, co
                            const int32_t *tied, srx_decode_plan **out);
 int srx_decode_plan_set_transitions(srx_decode_plan *plan, const float *tr_logp);
 void srx_decode_plan_destroy(srx_decode_plan *plan);
+/* How srx_viterbi_graph_dev walks the HMM (same results, bit for bit).  SRX_DECODE_DENSE: every state every frame, one
+ * workgroup per utterance, int32 back-pointers [frames][n_states] -- small lexica, many utterances at once.
+ * SRX_DECODE_FRONTIER: per frame only the states inside the beam (the reference's `layer` map restricted to what
+ * src/hmm.cpp:165 lets through) push their transitions; back-pointers are kept per frontier member (8 bytes each), so the
+ * memory follows the beam, not frames * n_states; the whole GPU works on one frame -- the full lexicon of
+ * src/main.cpp:58 (about 10^6 states).  SRX_DECODE_AUTO (default): dense up to 32,768 states and 256 MB of back-pointers.
+ * max_workspace_bytes (0: keep, default 2 GiB) bounds the frontier sweep's workspace; an utterance whose frontier outgrows
+ * its share gets status 3.  No counterpart in the reference (a tuning knob). */
+enum { SRX_DECODE_AUTO = 0, SRX_DECODE_DENSE = 1, SRX_DECODE_FRONTIER = 2 };
+int srx_decode_plan_set_sweep(srx_decode_plan *plan, int sweep, size_t max_workspace_bytes);
 
 /* hmm::viterbi  src/hmm.cpp:150-224 on that HMM, for every utterance of a batch (frame_off: HOST array [n_utt+1], frames
  * counted over the emission matrix as in srx_viterbi_batch_dev): beam search with `beam_width` (src/hmm.cpp:165), `logp`
@@ -364,9 +374,9 @@ void srx_decode_plan_destroy(srx_decode_plan *plan);
  * index.  final_mode 0: the path must end in the last state, as the reference is compiled (src/hmm.cpp:210-215);
  * final_mode 1: it ends in the best active state above -1e10f, the recognition variant the reference has commented out
  * (src/hmm.cpp:196-209; its `throw 1729` is status 1 here).  Outputs: path[frames] (state indices), final_logp[n_utt],
- * final_state[n_utt] (may be NULL), status[n_utt] (0 ok, 1 NO PATH).  Score and path are bit-identical to the CPU
- * restatement (PARITY UNPINNED: the reference never runs Viterbi on its lexicon HMM).  Back-pointers take
- * 4 * frames * n_states bytes of the context's workspace. */
+ * final_state[n_utt] (may be NULL), status[n_utt] (0 ok, 1 NO PATH, 3 the frontier sweep ran out of its workspace share:
+ * see srx_decode_plan_set_sweep).  Score and path are bit-identical to the CPU restatement (PARITY UNPINNED: the reference
+ * never runs Viterbi on its lexicon HMM).  Workspace: see srx_decode_plan_set_sweep. */
 int srx_viterbi_graph_dev(srx_ctx *ctx, const srx_decode_plan *plan, const float *emis_dev, int64_t stride_t, int64_t stride_g,
                           const int64_t *frame_off, int n_utt, float beam_width, int final_mode, int32_t *path_dev,
                           float *final_logp_dev, int32_t *final_state_dev, int32_t *status_dev);

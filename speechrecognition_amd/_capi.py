@@ -112,6 +112,7 @@ SIGNATURES = {
     "srx_decode_plan_create": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.POINTER(vp)]),
     "srx_decode_plan_set_transitions": (C.c_int, [vp, vp]),
     "srx_decode_plan_destroy": (None, [vp]),
+    "srx_decode_plan_set_sweep": (C.c_int, [vp, C.c_int, C.c_size_t]),
     "srx_viterbi_graph_dev": (C.c_int, [vp, vp, vp, i64, i64, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp]),
     "srx_train_transitions_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp]),
     "srx_state_model_dev": (C.c_int, [vp, C.POINTER(srx_hmm_batch), vp, vp, vp, C.c_int, vp, vp]),

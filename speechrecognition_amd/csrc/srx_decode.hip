@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "srx_common.h"
+#include "srx_decode_plan.h"
 
 // ------------------------------------------------------------------------------------------ host: topology
 extern "C" int srx_hmm_build_lexicon(int n_words, const int32_t *phone_off, const int32_t *phones, const float *uni_logp, float lmsf,
@@ -95,19 +96,6 @@ extern "C" int srx_hmm_build_lexicon(int n_words, const int32_t *phone_off, cons
 }
 
 // ------------------------------------------------------------------------------------------ plan: the graph on the device
-static constexpr int FANOUT_MIN = 4;    // sources with at least this many transitions get a prefix pass
-static constexpr int FANIN_MIN = 17;    // targets with at least this many incoming edges are reduced by the whole workgroup
-
-struct srx_decode_plan {
-    srx_ctx *ctx = nullptr;
-    int n_states = 0, n_tr = 0, n_fan = 0, n_big = 0, n_pre = 0;
-    int32_t *tr_off = nullptr, *tr_tgt = nullptr, *tied = nullptr;
-    float *tr_logp = nullptr;
-    int32_t *in_off = nullptr, *in_src = nullptr, *in_k = nullptr, *in_pre = nullptr;   // incoming edges per target, sources descending
-    int32_t *fan_src = nullptr, *fan_pre = nullptr;                                   // fan-out sources and their offset in `pre`
-    int32_t *big_tgt = nullptr;                                                       // fan-in targets
-};
-
 template <class T>
 static hipError_t to_device(T **dst, const std::vector<T> &h) {
     hipError_t e = hipMalloc((void **)dst, (h.size() ? h.size() : 1) * sizeof(T));
@@ -120,6 +108,7 @@ extern "C" void srx_decode_plan_destroy(srx_decode_plan *p) {
     (void)hipFree(p->tr_off); (void)hipFree(p->tr_tgt); (void)hipFree(p->tied); (void)hipFree(p->tr_logp);
     (void)hipFree(p->in_off); (void)hipFree(p->in_src); (void)hipFree(p->in_k); (void)hipFree(p->in_pre);
     (void)hipFree(p->fan_src); (void)hipFree(p->fan_pre); (void)hipFree(p->big_tgt);
+    (void)hipFree(p->wide_of); (void)hipFree(p->wide_src); (void)hipFree(p->wide_pre); (void)hipFree(p->wpre_fan);
     delete p;
 }
 
@@ -162,8 +151,18 @@ extern "C" int srx_decode_plan_create(srx_ctx *ctx, int n_states, const int32_t 
         }
     for (int j = 0; j < n_states; j++)
         if (in_off[(size_t)j + 1] - in_off[j] >= FANIN_MIN) big_tgt.push_back(j);
+    std::vector<int32_t> wide_of((size_t)n_states, -1), wide_src, wide_pre, wpre_fan;
+    for (int s = 0; s < n_states; s++)
+        if (tr_off[s + 1] - tr_off[s] >= FR_FAN_MIN) {
+            wide_of[s] = (int32_t)wide_src.size();
+            wide_src.push_back(s);
+            wide_pre.push_back((int32_t)wpre_fan.size());
+            wpre_fan.insert(wpre_fan.end(), (size_t)(tr_off[s + 1] - tr_off[s]), wide_of[s]);
+        }
     srx_decode_plan *p = new srx_decode_plan();
     p->ctx = ctx;
+    p->n_wide = (int)wide_src.size();
+    p->n_wpre = (int)wpre_fan.size();
     p->n_states = n_states;
     p->n_tr = n_tr;
     p->n_fan = (int)fan_src.size();
@@ -177,7 +176,9 @@ extern "C" int srx_decode_plan_create(srx_ctx *ctx, int n_states, const int32_t 
         (e = to_device(&p->in_off, in_off)) != hipSuccess || (e = to_device(&p->in_src, in_src)) != hipSuccess ||
         (e = to_device(&p->in_k, in_k)) != hipSuccess || (e = to_device(&p->in_pre, in_pre)) != hipSuccess ||
         (e = to_device(&p->fan_src, fan_src)) != hipSuccess || (e = to_device(&p->fan_pre, fan_pre)) != hipSuccess ||
-        (e = to_device(&p->big_tgt, big_tgt)) != hipSuccess) {
+        (e = to_device(&p->big_tgt, big_tgt)) != hipSuccess || (e = to_device(&p->wide_of, wide_of)) != hipSuccess ||
+        (e = to_device(&p->wide_src, wide_src)) != hipSuccess || (e = to_device(&p->wide_pre, wide_pre)) != hipSuccess ||
+        (e = to_device(&p->wpre_fan, wpre_fan)) != hipSuccess) {
         srx_decode_plan_destroy(p);
         return srx_fail(ctx, e == hipErrorOutOfMemory ? SRX_ERR_NOMEM : SRX_ERR_DEVICE, "srx_decode_plan_create: %s", hipGetErrorString(e));
     }
@@ -192,6 +193,15 @@ extern "C" int srx_decode_plan_set_transitions(srx_decode_plan *p, const float *
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SRX_HIP(ctx, hipMemcpy(p->tr_logp, tr_logp, (size_t)p->n_tr * sizeof(float), hipMemcpyHostToDevice));
+    return SRX_OK;
+}
+
+extern "C" int srx_decode_plan_set_sweep(srx_decode_plan *p, int sweep, size_t max_workspace_bytes) {
+    if (!p) return SRX_ERR_INVALID;
+    srx_ctx *ctx = p->ctx;
+    SRX_REQUIRE(ctx, sweep == SRX_DECODE_AUTO || sweep == SRX_DECODE_DENSE || sweep == SRX_DECODE_FRONTIER, "srx_decode_plan_set_sweep: sweep %d", sweep);
+    p->sweep = sweep;
+    if (max_workspace_bytes) p->max_workspace = max_workspace_bytes;
     return SRX_OK;
 }
 
@@ -371,6 +381,12 @@ extern "C" int srx_viterbi_graph_dev(srx_ctx *ctx, const srx_decode_plan *plan, 
         SRX_REQUIRE(ctx, frame_off[u + 1] >= frame_off[u] && frame_off[u + 1] - frame_off[u] < (1ll << 31), "srx_viterbi_graph_dev: bad frame offsets");
         bp_off[(size_t)u + 1] = bp_off[u] + (frame_off[u + 1] - frame_off[u]) * n;
     }
+    // the dense sweep keeps one int32 back-pointer per (frame, state) and visits every state every frame: right for lexica of
+    // a few thousand states and many utterances at once; beyond that the frontier sweep (srx_decode_frontier.hip)
+    const bool dense_fits = n <= 32768 && (size_t)bp_off[n_utt] * 4 <= ((size_t)256 << 20);
+    if (plan->sweep == SRX_DECODE_FRONTIER || (plan->sweep == SRX_DECODE_AUTO && !dense_fits))
+        return srx_viterbi_frontier(ctx, plan, emis_dev, stride_t, stride_g, frame_off, n_utt, beam_width, final_mode, path_dev, final_logp_dev,
+                                    final_state_dev, status_dev);
     // workspace (slot 1, shared with the alignment kernel's back-pointers): frame and back-pointer offsets, delta, flags,
     // running values, back-pointers
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };

@@ -145,6 +145,7 @@ def frame_offsets(cfg, sample_off):
 
 
 MFCC_AUTO, MFCC_F32, MFCC_F16X3, MFCC_FFT = 0, 1, 2, 3
+DECODE_AUTO, DECODE_DENSE, DECODE_FRONTIER = 0, 1, 2
 
 
 class MfccPlan:
@@ -501,6 +502,10 @@ class GraphHmm:
 
     def set_transitions(self, tr_logp):
         check(self.ctx.lib.srx_decode_plan_set_transitions(self.h, _ptr(np.ascontiguousarray(tr_logp, np.float32))), self.ctx.h)
+
+    def set_sweep(self, sweep, max_workspace_bytes=0):
+        """DECODE_AUTO / DECODE_DENSE / DECODE_FRONTIER (srx_decode_plan_set_sweep): same results, different walk."""
+        check(self.ctx.lib.srx_decode_plan_set_sweep(self.h, int(sweep), int(max_workspace_bytes)), self.ctx.h)
 
     def viterbi(self, emis_d, stride_t, stride_g, frame_off, beam=1e10, final_mode=0):
         """-> (path [frames], final [n_utt], final_state [n_utt], status [n_utt]) as host arrays."""

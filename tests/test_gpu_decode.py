@@ -5,7 +5,10 @@ PARITY UNPINNED: the reference's main() never runs Viterbi on its lexicon HMM, t
 commented out there (src/hmm.cpp:196-209) and its unigram file is not in the repository.  The checker is the oracle's
 restatement of the same loops on an arbitrary transition list (orc_viterbi_graph), which reproduces the training-HMM
 oracle bit for bit on training topologies (tests/test_oracle_pins.py).  Bar: topology arrays identical; score bit-exact;
-path identical (the oracle visits sources in descending index, the kernel's tie rule)."""
+path identical (the oracle visits sources in descending index, the kernel's tie rule).  Both walks of srx_viterbi_graph_dev are
+held to it: the dense sweep and the frontier sweep (srx_decode_plan_set_sweep), the latter up to the size of the
+reference's own lexicon (src/main.cpp:58 reads the 133,860 lines of res/lexicon/cmu.txt; the file does not travel to the GPU
+box, so the words here are synthetic with its length distribution)."""
 import numpy as np
 import pytest
 
@@ -41,8 +44,9 @@ def _emissions_for(rng, lex, words, T_per_word, n_utt):
     return np.concatenate(emis), np.array(fo, np.int64)
 
 
+@pytest.mark.parametrize("sweep", [host.DECODE_DENSE, host.DECODE_FRONTIER])
 @pytest.mark.parametrize("n_words", [1, 10, 60, 500])
-def test_lexicon_hmm_topology_and_decode_bit_exact(ctx, oracle, n_words):
+def test_lexicon_hmm_topology_and_decode_bit_exact(ctx, oracle, n_words, sweep):
     rng = np.random.default_rng(100 + n_words)
     words, uni = _lexicon(rng, n_words)
     a = host.build_lexicon_hmm(words, uni)
@@ -55,6 +59,7 @@ def test_lexicon_hmm_topology_and_decode_bit_exact(ctx, oracle, n_words):
     assert a["tr_off"][1] == n_words and np.array_equal(a["tr_logp"][:n_words], np.float32(5.0) * uni)
     tied = a["ctx"][:, 1].copy()
     hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    hmm.set_sweep(sweep)
     emis, fo = _emissions_for(rng, a, words, 9, 6)
     emis_d = ctx.array(emis)
     for final_mode in (1, 0):
@@ -128,7 +133,8 @@ def test_update_states_on_lexicon_transitions(ctx, oracle):
     hmm.close()
 
 
-def test_graph_viterbi_edge_cases(ctx, oracle):
+@pytest.mark.parametrize("sweep", [host.DECODE_DENSE, host.DECODE_FRONTIER])
+def test_graph_viterbi_edge_cases(ctx, oracle, sweep):
     """Ragged and degenerate inputs: an empty batch, an utterance of zero frames (NO PATH), one frame, a beam that prunes
     everything but the best, and the compiled end condition on a lexicon HMM (the path must end in the LAST word's silence)."""
     rng = np.random.default_rng(9)
@@ -136,6 +142,7 @@ def test_graph_viterbi_edge_cases(ctx, oracle):
     a = host.build_lexicon_hmm(words, uni)
     tied = a["ctx"][:, 1].copy()
     hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    hmm.set_sweep(sweep)
     emis, _ = _emissions_for(rng, a, words, 6, 2)
     emis_d = ctx.array(emis)
     p, f, s, st = hmm.viterbi(emis_d, G, 1, np.array([0], np.int64), 1e10, 1)          # no utterances
@@ -155,4 +162,87 @@ def test_graph_viterbi_edge_cases(ctx, oracle):
                 if r["status"] == 0:
                     assert f[u].tobytes() == r["final"].tobytes() and s[u] == r["final_state"]
                     assert np.array_equal(p[fo[u]:fo[u + 1]], r["path"])
+    hmm.close()
+
+
+def _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, beam, final_mode, expect_ok=None):
+    path, final, fstate, status = hmm.viterbi(emis_d, G, 1, fo, beam, final_mode)
+    n_ok = 0
+    for u in range(len(fo) - 1):
+        r = oracle.viterbi_graph(emis[fo[u]:fo[u + 1]], tied, a["tr_off"], a["tr_tgt"], a["tr_logp"], beam, 0, final_mode)
+        assert status[u] == r["status"], (final_mode, beam, u, status[u], r["status"])
+        if r["status"] == 0:
+            n_ok += 1
+            assert final[u].tobytes() == r["final"].tobytes(), (final_mode, beam, u, final[u], r["final"])
+            assert fstate[u] == r["final_state"]
+            assert np.array_equal(path[fo[u]:fo[u + 1]], r["path"]), (final_mode, beam, u)
+    if expect_ok is not None:
+        assert n_ok == expect_ok, (final_mode, beam, n_ok)
+    return path
+
+
+def test_graph_with_mixed_fanout_both_sweeps(ctx, oracle):
+    """A random graph whose sources have 1..80 transitions (both sides of the frontier sweep's in-thread / chain split at 33
+    and of the dense sweep's at 4), repeated targets within a source included."""
+    rng = np.random.default_rng(77)
+    n = 400
+    deg = rng.choice([1, 2, 3, 5, 20, 32, 33, 34, 80], n)
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum(deg)
+    tgt = rng.integers(0, n, off[-1]).astype(np.int32)
+    lp = (-rng.uniform(0.1, 3.0, off[-1])).astype(np.float32)
+    tied = rng.integers(0, G, n).astype(np.int32)
+    a = {"tr_off": off, "tr_tgt": tgt, "tr_logp": lp}
+    T = 40
+    emis = (rng.standard_normal((3 * T, G)) * 2 - 3).astype(np.float32)
+    fo = np.array([0, T, 2 * T, 3 * T], np.int64)
+    emis_d = ctx.array(emis)
+    for sweep in (host.DECODE_DENSE, host.DECODE_FRONTIER):
+        hmm = host.GraphHmm(ctx, off, tgt, lp, tied)
+        hmm.set_sweep(sweep)
+        for final_mode in (1, 0):
+            for beam in (1e10, 30.0, 5.0):
+                _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, beam, final_mode)
+        hmm.close()
+
+
+@pytest.mark.parametrize("n_words", [20000, 133860])
+def test_frontier_sweep_at_reference_lexicon_size_bit_exact(ctx, oracle, n_words):
+    """20,000 words, and 133,860 -- the line count of the reference's res/lexicon/cmu.txt, which
+    src/main.cpp:58 turns into one HMM of about 10^6 states.  Word lengths follow that lexicon (mean 6.4 phones, up to 20).
+    The start state's fan-out is one serial f32 chain over every word, as the reference carries `logp` (src/hmm.cpp:164-169);
+    with a beam of 200 only the head of that chain survives src/hmm.cpp:165, which is what bounds the frontier."""
+    rng = np.random.default_rng(n_words)
+    lens = np.clip(rng.poisson(5.4, n_words) + 1, 1, 20)
+    words = [rng.integers(1, 40, int(k)).astype(np.int32) for k in lens]
+    counts = rng.integers(1, 5000, n_words)
+    uni = (np.log(counts) - np.float32(np.log(counts.sum() * 3.0))).astype(np.float32)
+    a = host.build_lexicon_hmm(words, uni)
+    assert a["n_states"] == 1 + int(lens.sum()) + n_words
+    tied = a["ctx"][:, 1].copy()
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)      # AUTO: too many states for the dense sweep
+    # two utterances that spell words from the head of the lexicon (the only ones the carried logp leaves reachable)
+    emis, fo = [], [0]
+    for seq in ([0, 2, 1], [3, 0]):
+        rows = []
+        for w in seq:
+            for ph in list(words[w]) + [0]:
+                e = rng.standard_normal((int(rng.integers(2, 6)), G)).astype(np.float32) * 2 - 12
+                e[:, ph] += 9.0
+                rows.append(e)
+        emis.append(np.concatenate(rows))
+        fo.append(fo[-1] + len(emis[-1]))
+    emis, fo = np.concatenate(emis), np.array(fo, np.int64)
+    emis_d = ctx.array(emis)
+    _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 200.0, 1, expect_ok=2)     # the beam VERDICT r02 item 5 names
+    _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 200.0, 0)
+    if n_words == 20000:
+        _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 1e10, 1, expect_ok=2)  # nothing pruned: every layer in the store
+        _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 1e10, 0)
+    # a workspace limit too small for the unpruned layers: status 3, not a fault
+    hmm.set_sweep(host.DECODE_FRONTIER, 64 << 20 if n_words == 20000 else 400 << 20)
+    _, _, _, st = hmm.viterbi(emis_d, G, 1, fo, 1e10, 1)
+    assert list(st) == [3, 3]
+    path, final, _, st = hmm.viterbi(emis_d, G, 1, fo, 200.0, 1)
+    assert list(st) == [0, 0]
     hmm.close()
