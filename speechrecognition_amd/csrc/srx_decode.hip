@@ -108,7 +108,7 @@ extern "C" void srx_decode_plan_destroy(srx_decode_plan *p) {
     (void)hipFree(p->tr_off); (void)hipFree(p->tr_tgt); (void)hipFree(p->tied); (void)hipFree(p->tr_logp);
     (void)hipFree(p->in_off); (void)hipFree(p->in_src); (void)hipFree(p->in_k); (void)hipFree(p->in_pre);
     (void)hipFree(p->fan_src); (void)hipFree(p->fan_pre); (void)hipFree(p->big_tgt);
-    (void)hipFree(p->wide_of); (void)hipFree(p->wide_src); (void)hipFree(p->wide_pre); (void)hipFree(p->wpre_fan);
+    (void)hipFree(p->wide_of); (void)hipFree(p->wide_src); (void)hipFree(p->wide_pre); (void)hipFree(p->wpre_fan); (void)hipFree(p->wpre_tied);
     delete p;
 }
 
@@ -151,13 +151,14 @@ extern "C" int srx_decode_plan_create(srx_ctx *ctx, int n_states, const int32_t 
         }
     for (int j = 0; j < n_states; j++)
         if (in_off[(size_t)j + 1] - in_off[j] >= FANIN_MIN) big_tgt.push_back(j);
-    std::vector<int32_t> wide_of((size_t)n_states, -1), wide_src, wide_pre, wpre_fan;
+    std::vector<int32_t> wide_of((size_t)n_states, -1), wide_src, wide_pre, wpre_fan, wpre_tied;
     for (int s = 0; s < n_states; s++)
         if (tr_off[s + 1] - tr_off[s] >= FR_FAN_MIN) {
             wide_of[s] = (int32_t)wide_src.size();
             wide_src.push_back(s);
             wide_pre.push_back((int32_t)wpre_fan.size());
             wpre_fan.insert(wpre_fan.end(), (size_t)(tr_off[s + 1] - tr_off[s]), wide_of[s]);
+            for (int ti = tr_off[s]; ti < tr_off[s + 1]; ti++) wpre_tied.push_back(tied[tr_tgt[ti]]);
         }
     srx_decode_plan *p = new srx_decode_plan();
     p->ctx = ctx;
@@ -178,7 +179,7 @@ extern "C" int srx_decode_plan_create(srx_ctx *ctx, int n_states, const int32_t 
         (e = to_device(&p->fan_src, fan_src)) != hipSuccess || (e = to_device(&p->fan_pre, fan_pre)) != hipSuccess ||
         (e = to_device(&p->big_tgt, big_tgt)) != hipSuccess || (e = to_device(&p->wide_of, wide_of)) != hipSuccess ||
         (e = to_device(&p->wide_src, wide_src)) != hipSuccess || (e = to_device(&p->wide_pre, wide_pre)) != hipSuccess ||
-        (e = to_device(&p->wpre_fan, wpre_fan)) != hipSuccess) {
+        (e = to_device(&p->wpre_fan, wpre_fan)) != hipSuccess || (e = to_device(&p->wpre_tied, wpre_tied)) != hipSuccess) {
         srx_decode_plan_destroy(p);
         return srx_fail(ctx, e == hipErrorOutOfMemory ? SRX_ERR_NOMEM : SRX_ERR_DEVICE, "srx_decode_plan_create: %s", hipGetErrorString(e));
     }

@@ -46,7 +46,7 @@ struct FrArgs {
     const int32_t *tr_off, *tr_tgt, *tied;
     const float *tr_logp;
     int n_wide, n_wpre;
-    const int32_t *wide_of, *wide_src, *wide_pre, *wpre_fan;
+    const int32_t *wide_of, *wide_src, *wide_pre, *wpre_fan, *wpre_tied;
     const float *emis;
     int64_t st_t, st_g;
     const int64_t *foff;            // [U + 1] frame offsets of the utterances in flight
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fr_push(FrArgs a, int t) {
 
 // the running values of a wide member: one lane, in order; the wave stages the operands
 __global__ __launch_bounds__(64) void k_fr_chain(FrArgs a, int t) {
-    __shared__ __align__(16) float s_lp[2][FR_TILE], s_e[2][FR_TILE];
+    __shared__ __align__(16) float s_lp[FR_TILE], s_e[FR_TILE], s_x[FR_TILE];
     const int u = blockIdx.y, fi = blockIdx.x, lane = threadIdx.x;
     const int64_t f0 = a.foff[u];
     const int T = (int)(a.foff[u + 1] - f0);
@@ -169,48 +169,71 @@ __global__ __launch_bounds__(64) void k_fr_chain(FrArgs a, int t) {
     float x = a.fval[((size_t)u * 2 + (t & 1)) * a.n + (wp - 1)];
     float best = -1e10f;
     constexpr int PER = FR_TILE / 64;
+    // Operands travel two tiles ahead of the chain, without a branch (indices clamped to the last transition), so that no
+    // load is waited for where it is issued: emission columns (contiguous, made at plan creation) for tile k+2, the gathered
+    // emission scores and the transition scores for tile k+1, while lane 0 adds up tile k.
+    const int32_t *wt = a.wpre_tied + a.wide_pre[fi];
+    int r_ix[PER];
     float r_lp[PER], r_e[PER];
+    auto fetch_ix = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) r_ix[i] = wt[min(k0 + i * 64 + lane, K - 1)];
+    };
     auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            const int k = k0 + i * 64 + lane;
-            if (k < K) {
-                r_lp[i] = a.tr_logp[t0 + k];
-                r_e[i] = e_t[(int64_t)a.tied[a.tr_tgt[t0 + k]] * a.st_g];
-            }
+            r_lp[i] = a.tr_logp[t0 + min(k0 + i * 64 + lane, K - 1)];
+            r_e[i] = e_t[(int64_t)r_ix[i] * a.st_g];
         }
     };
+    fetch_ix(0);
     fetch(0);
-    for (int k0 = 0, b = 0; k0 < K; k0 += FR_TILE, b ^= 1) {
+    fetch_ix(FR_TILE);
+    for (int k0 = 0; k0 < K; k0 += FR_TILE) {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
-            s_lp[b][i * 64 + lane] = r_lp[i];
-            s_e[b][i * 64 + lane] = r_e[i];
+            s_lp[i * 64 + lane] = r_lp[i];
+            s_e[i * 64 + lane] = r_e[i];
         }
         __syncthreads();
-        if (k0 + FR_TILE < K) fetch(k0 + FR_TILE);     // in flight while the chain runs
+        fetch(k0 + FR_TILE);                           // in flight while the chain runs
+        fetch_ix(k0 + 2 * FR_TILE);
         const int m = min(FR_TILE, K - k0);
         if (lane == 0) {
-            int i = 0;
-            for (; i + 4 <= m; i += 4) {
-                const float4 l4 = *reinterpret_cast<const float4 *>(&s_lp[b][i]);
-                float4 e4 = *reinterpret_cast<const float4 *>(&s_e[b][i]);
-                x = x + l4.x; x = x + e4.x; e4.x = x; best = fmaxf(best, x);
-                x = x + l4.y; x = x + e4.y; e4.y = x; best = fmaxf(best, x);
-                x = x + l4.z; x = x + e4.z; e4.z = x; best = fmaxf(best, x);
-                x = x + l4.w; x = x + e4.w; e4.w = x; best = fmaxf(best, x);
-                *reinterpret_cast<float4 *>(&s_e[b][i]) = e4;
+            // the serial part: two dependent f32 additions per transition (src/hmm.cpp:167-168).  Operands are read two
+            // quads ahead of the additions that use them; results go to an array of their own, so that nothing orders the
+            // reads behind the writes.
+            const float4 *lp4 = reinterpret_cast<const float4 *>(s_lp), *e4 = reinterpret_cast<const float4 *>(s_e);
+            float4 *x4 = reinterpret_cast<float4 *>(s_x);
+            const int nq = m >> 2;
+            float4 l0 = lp4[0], e0 = e4[0], l1 = lp4[1], e1 = e4[1];     // the arrays hold FR_TILE >= 8 floats whatever m is
+#pragma unroll 4
+            for (int q = 0; q < nq; q++) {
+                const int qn = min(q + 2, FR_TILE / 4 - 1);
+                const float4 l2 = lp4[qn], e2 = e4[qn];
+                float4 o;
+                x = x + l0.x; x = x + e0.x; o.x = x;
+                x = x + l0.y; x = x + e0.y; o.y = x;
+                x = x + l0.z; x = x + e0.z; o.z = x;
+                x = x + l0.w; x = x + e0.w; o.w = x;
+                x4[q] = o;
+                l0 = l1; e0 = e1; l1 = l2; e1 = e2;
             }
-            for (; i < m; i++) {
-                x = x + s_lp[b][i];
-                x = x + s_e[b][i];
-                s_e[b][i] = x;
-                best = fmaxf(best, x);
+            for (int i = nq * 4; i < m; i++) {
+                x = x + s_lp[i];
+                x = x + s_e[i];
+                s_x[i] = x;
             }
         }
         __syncthreads();
-        for (int i = lane; i < m; i += 64) pre[k0 + i] = s_e[b][i];
+        for (int i = lane; i < m; i += 64) {
+            const float v = s_x[i];
+            pre[k0 + i] = v;
+            best = fmaxf(best, v);
+        }
+        __syncthreads();
     }
+    for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
     if (lane == 0 && best > -1e10f) atomicMax(&a.ctl[u].best_bits, f2o(best));
 }
 
@@ -398,7 +421,7 @@ int srx_viterbi_frontier(srx_ctx *ctx, const srx_decode_plan *plan, const float 
         a.n = (int)n;
         a.tr_off = plan->tr_off; a.tr_tgt = plan->tr_tgt; a.tied = plan->tied; a.tr_logp = plan->tr_logp;
         a.n_wide = plan->n_wide; a.n_wpre = plan->n_wpre;
-        a.wide_of = plan->wide_of; a.wide_src = plan->wide_src; a.wide_pre = plan->wide_pre; a.wpre_fan = plan->wpre_fan;
+        a.wide_of = plan->wide_of; a.wide_src = plan->wide_src; a.wide_pre = plan->wide_pre; a.wpre_fan = plan->wpre_fan; a.wpre_tied = plan->wpre_tied;
         a.emis = emis_dev; a.st_t = stride_t; a.st_g = stride_g;
         a.beam = beam_width; a.final_mode = final_mode;
         a.foff = reinterpret_cast<const int64_t *>(w); w += head;

@@ -21,6 +21,7 @@ struct srx_decode_plan {
     int32_t *wide_src = nullptr;      // [n_wide] state
     int32_t *wide_pre = nullptr;      // [n_wide] offset of the source's transitions in the flattened list
     int32_t *wpre_fan = nullptr;      // [n_wpre] wide source of every flattened transition
+    int32_t *wpre_tied = nullptr;     // [n_wpre] emission column of its target
     int sweep = 0;                    // SRX_DECODE_AUTO / DENSE / FRONTIER
     size_t max_workspace = (size_t)2 << 30;
 };

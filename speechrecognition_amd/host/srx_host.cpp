@@ -1171,6 +1171,8 @@ path hmm::run_graph(vector<featurevec *> &fvs, float &prevp, float beam_width, i
     check(srx_viterbi_graph_dev(ctx, dplan, d_e.p, G, 1, fo, 1, beam_width, final_mode, d_path.p, d_final.p, d_fs.p, d_status.p));
     int32_t status = 0;
     d_status.download(&status, 1);
+    if (status == 3)   // not a property of the utterance: the frontier sweep's store is too small for this beam
+        throw srx_error(SRX_ERR_NOMEM, "hmm::viterbi: the beam keeps more states than the decode workspace holds (srx_decode_plan_set_sweep)");
     if (status != 0) {
         if (srx::verbose()) std::cout << "NO PATH" << std::endl;
         return result;

@@ -428,44 +428,70 @@ def test_headless_driver_prompts_through_the_lexicon(ctx, oracle, tmp_path):
     outw = _run([SRX, "--mode", "decode", "--voxforge", root, "--model", root + "mfin.txt", "--lexicon", lex[0], "--prefixes", lex[1],
                  "--suffixes", lex[2], "--beam", "250", "--unigram-total", "1000"], env)
     rows_w = [ln.split() for ln in outw.splitlines() if ln and ln[0].isdigit()]
-    # the lexicon as the reference's map holds it: spelling -> first pronunciation, sorted by spelling
-    # (through the oracle's lexicon parser, which restates the reference's quirks: alternates "(1)" fold into the word and
-    #  only the first listed pronunciation is used, src/hmm.cpp:96; a line ending in blanks repeats its last phone)
-    entries = {w: np.array(p[0], np.int32) for w, p in pr.main.items() if len(p[0]) > 0}
-    spell = sorted(entries)
-    uni = np.full(len(spell), -np.float32(np.log(1000.0)), np.float32)        # an empty unigram table: -logtotal for every word
-    L = oracle.build_lexicon_hmm([entries[w] for w in spell], uni)
-    assert ("lexicon-hmm %d states" % L["n_states"]) in out
-    tied = L["ctx"][:, 1].copy()                       # NULL_CONTEXT ties: the tied state of a context is its phone
     model = host.AcousticModel(ctx, 40, 1, 13)
     model.set(gm, gv, gw)
-    used = [(f2, name) for fo_ in folders for (f2, name) in sorted(samples) if f2 == fo_]
-    assert len(rows) == 5 == len(rows_w)
-    n_words_seen = 0
-    ui = 0
-    for (f2, name), text in zip(used, texts):
-        try:
-            pr.pronounce(text)
-        except P.Unpronounceable:
-            continue                                   # the driver skipped this utterance ("Caught exception 1")
-        feats = oracle.read_features(_read_mfc(os.path.join(root, f2, "mfc", name)), 2)
-        e = model.score(feats, SRX_MIX_COMPONENT0, SRX_SCORE_EXACT)
-        r = oracle.viterbi_graph(e, tied, L["tr_off"], L["tr_tgt"], L["tr_logp"], 250.0, 0, 1)
-        row = rows[ui]
-        if r["status"] != 0:
-            assert len(row) == 2
-        else:
-            assert [int(v) for v in row[2:]] == list(r["path"]), ui
-            assert abs(float(row[1]) - float(r["final"]) / len(feats)) <= 1e-6 * abs(float(r["final"]) / len(feats))
-            # the word line: a word is counted when the path enters its first state
-            first = np.flatnonzero((L["word_of"] >= 0) & (np.roll(L["word_of"], 1) != L["word_of"]))
-            p_ = r["path"]
-            enter = [p_[0]] + [b_ for a_, b_ in zip(p_[:-1], p_[1:]) if a_ != b_]
-            want = [spell[L["word_of"][s_]] for s_ in enter if s_ in first]
-            assert rows_w[ui][2:] == want, ui
-            n_words_seen += len(want)
-        ui += 1
-    assert ui == 5 and n_words_seen >= 5
+
+    def check_decode(pr, out, rows, rows_w, beam):
+        # the lexicon as the reference's map holds it: spelling -> first pronunciation, sorted by spelling
+        # (through the oracle's lexicon parser, which restates the reference's quirks: alternates "(1)" fold into the word and
+        #  only the first listed pronunciation is used, src/hmm.cpp:96; a line ending in blanks repeats its last phone)
+        entries = {w: np.array(p[0], np.int32) for w, p in pr.main.items() if len(p[0]) > 0}
+        spell = sorted(entries)
+        uni = np.full(len(spell), -np.float32(np.log(1000.0)), np.float32)        # an empty unigram table: -logtotal for every word
+        L = oracle.build_lexicon_hmm([entries[w] for w in spell], uni)
+        assert ("lexicon-hmm %d states" % L["n_states"]) in out
+        tied = L["ctx"][:, 1].copy()                       # NULL_CONTEXT ties: the tied state of a context is its phone
+        used = [(f2, name) for fo_ in folders for (f2, name) in sorted(samples) if f2 == fo_]
+        assert len(rows) == 5 == len(rows_w)
+        n_words_seen = 0
+        ui = 0
+        for (f2, name), text in zip(used, texts):
+            try:
+                pr.pronounce(text)
+            except P.Unpronounceable:
+                continue                                   # the driver skipped this utterance ("Caught exception 1")
+            feats = oracle.read_features(_read_mfc(os.path.join(root, f2, "mfc", name)), 2)
+            e = model.score(feats, SRX_MIX_COMPONENT0, SRX_SCORE_EXACT)
+            r = oracle.viterbi_graph(e, tied, L["tr_off"], L["tr_tgt"], L["tr_logp"], beam, 0, 1)
+            row = rows[ui]
+            if r["status"] != 0:
+                assert len(row) == 2
+            else:
+                assert [int(v) for v in row[2:]] == list(r["path"]), ui
+                assert abs(float(row[1]) - float(r["final"]) / len(feats)) <= 1e-6 * abs(float(r["final"]) / len(feats))
+                # the word line: a word is counted when the path enters its first state
+                first = np.flatnonzero((L["word_of"] >= 0) & (np.roll(L["word_of"], 1) != L["word_of"]))
+                p_ = r["path"]
+                enter = [p_[0]] + [b_ for a_, b_ in zip(p_[:-1], p_[1:]) if a_ != b_]
+                want = [spell[L["word_of"][s_]] for s_ in enter if s_ in first]
+                assert rows_w[ui][2:] == want, ui
+                n_words_seen += len(want)
+            ui += 1
+        assert ui == 5
+        return n_words_seen, L["n_states"]
+
+    assert check_decode(pr, out, rows, rows_w, 250.0)[0] >= 5
+
+    # ---- the same at the size of the reference's own lexicon (src/main.cpp:27, 58: res/lexicon/cmu.txt, 133,860 lines, about
+    # 10^6 HMM states; the file does not travel to the GPU box, so the extra words are synthetic, with its length distribution,
+    # spelled to sort after the real ones).  hmm::decode goes through the frontier sweep here (srx_decode_frontier.hip): bounded
+    # memory -- the dense sweep would need 4 * frames * states bytes of back-pointers, 0.75 GB for the longest utterance.
+    big = root + "big_lexicon.txt"
+    with open(big, "w") as f:
+        f.write(open(lex[0]).read())
+        lens = np.clip(rng.poisson(5.4, 133860 - 26) + 1, 1, 20)
+        names = [n for n in PHONE_NAMES[1:40]]
+        for k, ln in enumerate(lens):
+            f.write("ZZW%06d  %s\n" % (k, " ".join(names[i] for i in rng.integers(0, len(names), int(ln)))))
+    prb = P.load(big, lex[1], lex[2])
+    cmd = [SRX, "--mode", "decode", "--voxforge", root, "--model", root + "mfin.txt", "--lexicon", big, "--prefixes", lex[1],
+           "--suffixes", lex[2], "--beam", "200", "--unigram-total", "1000"]
+    out_b = _run(cmd + ["--states"], env)
+    outw_b = _run(cmd, env)
+    rows_b = [ln.split() for ln in out_b.splitlines() if ln and ln[0].isdigit()]
+    rows_wb = [ln.split() for ln in outw_b.splitlines() if ln and ln[0].isdigit()]
+    seen, n_states = check_decode(prb, out_b, rows_b, rows_wb, 200.0)
+    assert n_states > 900000 and seen >= 5
     model.close()
 
 
