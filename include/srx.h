@@ -275,7 +275,7 @@ typedef struct {
     const int32_t *tied_dev;      /* [n_states] column of the emission matrix for each state */
     const int32_t *ntr_dev;       /* [n_states] 1..3 */
     float *trlogp_dev;            /* [n_states][3] (mutated by srx_train_transitions_dev) */
-    int max_states;               /* max over utterances of S (host-known; <= 256) */
+    int max_states;               /* max over utterances of S (host-known) */
     int64_t total_frames;         /* frame_off[n_utt] (host-known) */
 } srx_hmm_batch;
 
@@ -283,7 +283,10 @@ typedef struct {
  * emis[t*stride_t + tied[s]*stride_g] = (*acm)(*fvs[t], states[s].ctx), t counted over the whole
  * batch (the strides of srx_gmm_score_dev).  Outputs: path[total_frames]
  * (state index within the utterance), final_logp[n_utt] (= curr[best]), status[n_utt]
- * (0 ok, 1 "NO PATH": path/final untouched; 2: the utterance has more states than hmm->max_states, nothing computed).
+ * (0 ok, 1 "NO PATH": path/final untouched; 2: the utterance has more than SRX_VITERBI_MAX_STATES = 512 states, or more
+ * than the 64 / 128 / 256 / 512 that hmm->max_states sized the launch for: nothing computed -- take it through
+ * srx_viterbi_graph_dev, which has no limit and gives the same score and path; hmm::viterbi / hmm::train of the host layer
+ * do.  The reference has no limit, src/hmm.cpp:56-88).
  * prevp of the reference = final_logp / T.
  * Score is bit-exact w.r.t. the reference's f32 add order (it accumulates logp across a source's
  * transitions, src/hmm.cpp:164-169); exact ties are resolved towards the higher source index
@@ -293,6 +296,7 @@ typedef struct {
  * result is NO PATH): the kernel runs without the test and repeats an utterance with it when some score left +-2.5e9.
  * Fastest layout: state-major with 16-byte aligned rows (stride_t == 1, stride_g a multiple of 4, emis_dev 16-byte
  * aligned): four frames per load. */
+enum { SRX_VITERBI_MAX_STATES = 512 };
 int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *emis_dev, int64_t stride_t,
                           int64_t stride_g, float beam_width, int32_t *path_dev, float *final_logp_dev, int32_t *status_dev);
 
@@ -302,7 +306,7 @@ int srx_viterbi_batch_dev(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
  * context's grow-only workspace) live in a fixed array inside the library instead, SRX_VITERBI_NOALLOC_MAX_WORDS 32-bit
  * words (32 MiB) on every GPU the library runs on, held until the process ends.  The call performs no hipMalloc / hipFree
  * and creates no events (it is not recorded by srx_profile_*).  A batch needs
- *   (total_frames / 16 + n_utt + 1) * 64 * spl words,  spl = 1, 2, 4 for max_states <= 64, 128, 256;
+ *   (total_frames / 16 + n_utt + 1) * 64 * spl words,  spl = 1, 2, 4, 8 for max_states <= 64, 128, 256, more;
  * a larger batch is refused with SRX_ERR_INVALID (use srx_viterbi_batch_dev, or split the batch).  All calls on one GPU
  * share that GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race -- serialise them. */
 enum { SRX_VITERBI_NOALLOC_MAX_WORDS = 8 * 1024 * 1024 };

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64, OCC) void k_viterbi(int n_utt, const int64_t *_
                                                 const int64_t *__restrict__ ebase, float beam, uint32_t *__restrict__ bpws, int32_t *__restrict__ path,
                                                 float *__restrict__ final_logp, int32_t *__restrict__ status) {
     constexpr int SLMAX = 64 * SPLMAX;
-    constexpr int BT_CH = VitCfg<OCC>::BT_CH;
+    constexpr int BT_CH = SPLMAX >= 8 ? 16 : VitCfg<OCC>::BT_CH;   // 64 KB of LDS at most
     __shared__ int dmin[SLMAX + 2];
     __shared__ int s_ntr[SLMAX];
     __shared__ uint32_t s_bp[BT_CH * SLMAX];
@@ -522,15 +522,16 @@ __global__ __launch_bounds__(64, OCC) void k_viterbi(int n_utt, const int64_t *_
 __global__ __launch_bounds__(256) void k_train_transitions(int n_utt, const int64_t *__restrict__ foff,
                                                            const int32_t *__restrict__ soff, const int32_t *__restrict__ ntr,
                                                            float *__restrict__ trlogp, const int32_t *__restrict__ path,
-                                                           const int32_t *__restrict__ status) {
+                                                           const int32_t *__restrict__ status, int max_states) {
     const int u = blockIdx.x;
     if (u >= n_utt || status[u] != 0) return;
     const int64_t f0 = foff[u];
     const int T = (int)(foff[u + 1] - f0);
     const int s0 = soff[u];
     const int S = soff[u + 1] - s0;
-    __shared__ int cnt[256];
-    for (int s = threadIdx.x; s < 256; s += blockDim.x) cnt[s] = 0;
+    if (S > max_states) return;       // wider than the batch said it was: never index past the counters
+    extern __shared__ int cnt[];      // [max_states]
+    for (int s = threadIdx.x; s < S; s += blockDim.x) cnt[s] = 0;
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += blockDim.x) atomicAdd(&cnt[path[f0 + t]], 1);
     __syncthreads();
@@ -573,11 +574,13 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
     SRX_REQUIRE(ctx, emis_dev && path_dev && final_logp_dev && status_dev, "srx_viterbi_batch_dev: null argument");
     SRX_REQUIRE(ctx, hmm->frame_off_dev && hmm->state_off_dev && hmm->tied_dev && hmm->ntr_dev && hmm->trlogp_dev,
                 "srx_viterbi_batch_dev: null hmm field");
-    SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 256,
-                "srx_viterbi_batch_dev: max_states %d outside 1..256", hmm->max_states);
+    SRX_REQUIRE(ctx, hmm->max_states >= 1, "srx_viterbi_batch_dev: max_states %d", hmm->max_states);
     const int64_t total_frames = hmm->total_frames;
     SRX_REQUIRE(ctx, total_frames >= 0, "srx_viterbi_batch_dev: negative total_frames");
-    const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : 4);
+    // 1, 2, 4 or 8 states per lane: up to SRX_VITERBI_MAX_STATES = 512 states per utterance.  A batch may hold wider
+    // utterances (max_states says so): each of those gets status 2 and nothing else, and the caller takes it through
+    // srx_viterbi_graph_dev, which has no limit (hmm::viterbi of the host layer does)
+    const int spl = hmm->max_states <= 64 ? 1 : (hmm->max_states <= 128 ? 2 : (hmm->max_states <= 256 ? 4 : 8));
     const size_t words = viterbi_words(hmm, spl);
     void *ws = bp_words;
     if (bp_words) {
@@ -601,13 +604,19 @@ static int viterbi_launch(srx_ctx *ctx, const srx_hmm_batch *hmm, const float *e
 #define SRX_VIT2(SPLV, BEAMV, LAYV)                                                                                       \
     do { if (many) SRX_VIT3(SPLV, BEAMV, LAYV, 4); else SRX_VIT3(SPLV, BEAMV, LAYV, 1); } while (0)
 #define SRX_VIT3(SPLV, BEAMV, LAYV, OCCV)                                                                                 \
-    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, LAYV, (LAYV == 1 ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF), OCCV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
+    hipLaunchKernelGGL((k_viterbi<SPLV, BEAMV, LAYV, (SPLV >= 8 ? 16 : LAYV == 1 ? (SPLV <= 2 ? SRX_VIT_PF_VEC : 16) : SRX_VIT_PF), OCCV>), grid, block, 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,      \
                        hmm->state_off_dev, hmm->tied_dev, hmm->ntr_dev, hmm->trlogp_dev, emis_dev, stride_t, stride_g, ebase_dev, beam_width, \
                        (uint32_t *)ws, path_dev, final_logp_dev, status_dev)
     auto launch = [&]() {
         if (spl == 1) { if (beam) SRX_VIT(1, true); else SRX_VIT(1, false); }
         else if (spl == 2) { if (beam) SRX_VIT(2, true); else SRX_VIT(2, false); }
-        else { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
+        else if (spl == 4) { if (beam) SRX_VIT(4, true); else SRX_VIT(4, false); }
+        else {
+            // eight states per lane: the rare wide utterance.  Only the pruning body (it is the general one: a beam of 1e10
+            // prunes nothing) and only the one-wave-per-SIMD build are compiled for it -- the body needs the whole register
+            // file and still spills on the strided layouts
+            if (vec) SRX_VIT3(8, true, 1, 1); else if (ebase_dev) SRX_VIT3(8, true, 2, 1); else SRX_VIT3(8, true, 0, 1);
+        }
     };
     if (bp_words) {
         launch();   // no event pair: creating one allocates
@@ -686,11 +695,12 @@ extern "C" int srx_train_transitions_dev(srx_ctx *ctx, const srx_hmm_batch *hmm,
     SRX_REQUIRE(ctx, hmm && hmm->n_utt >= 0, "srx_train_transitions_dev: null or negative batch");
     if (hmm->n_utt == 0) return SRX_OK;
     SRX_REQUIRE(ctx, path_dev && status_dev, "srx_train_transitions_dev: null argument");
-    SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 256, "srx_train_transitions_dev: max_states outside 1..256");
+    // one LDS counter per state of the widest utterance (64 KB without opting in to more: 16,384 states)
+    SRX_REQUIRE(ctx, hmm->max_states >= 1 && hmm->max_states <= 16384, "srx_train_transitions_dev: max_states %d outside 1..16384", hmm->max_states);
     {
         SrxProf prof_(ctx, "k_train_transitions");
-        hipLaunchKernelGGL(k_train_transitions, dim3(hmm->n_utt), dim3(256), 0, ctx->stream, hmm->n_utt, hmm->frame_off_dev,
-                           hmm->state_off_dev, hmm->ntr_dev, hmm->trlogp_dev, path_dev, status_dev);
+        hipLaunchKernelGGL(k_train_transitions, dim3(hmm->n_utt), dim3(256), (size_t)hmm->max_states * sizeof(int), ctx->stream, hmm->n_utt, hmm->frame_off_dev,
+                           hmm->state_off_dev, hmm->ntr_dev, hmm->trlogp_dev, path_dev, status_dev, hmm->max_states);
     }
     SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;

@@ -1138,6 +1138,31 @@ hmm::hmm(pronlex &pr, unigram_model &uni, acoustic_model *ac, state_model *smo)
 }
 hmm::~hmm() { srx_decode_plan_destroy(dplan); }
 
+void hmm::ensure_dplan(const float *tr_lp_now) {
+    srx_ctx *ctx = srx::context();
+    if (dplan && tr_lp_now) {
+        check(srx_decode_plan_set_transitions(dplan, tr_lp_now));
+        return;
+    }
+    vector<int32_t> tr_off(1, 0), tr_tgt, tied;
+    vector<float> tr_lp;
+    for (hmm_state &st : states) {
+        for (transition &t : st.tr) {
+            if (!dplan) tr_tgt.push_back(indexOf(t.first));
+            tr_lp.push_back(t.second);
+        }
+        if (!dplan) {
+            tr_off.push_back((int32_t)tr_tgt.size());
+            tied.push_back(acm->tied_index(st.ctx));
+        }
+    }
+    if (dplan) {
+        check(srx_decode_plan_set_transitions(dplan, tr_lp.data()));
+        return;
+    }
+    check(srx_decode_plan_create(ctx, (int)states.size(), tr_off.data(), tr_tgt.data(), tr_lp_now ? tr_lp_now : tr_lp.data(), tied.data(), &dplan));
+}
+
 path hmm::run_graph(vector<featurevec *> &fvs, float &prevp, float beam_width, int final_mode) {
     path result;
     const int64_t T = (int64_t)fvs.size();
@@ -1146,19 +1171,9 @@ path hmm::run_graph(vector<featurevec *> &fvs, float &prevp, float beam_width, i
         return result;
     }
     srx_ctx *ctx = srx::context();
-    if (!dplan) {
-        vector<int32_t> tr_off(1, 0), tr_tgt, tied;
-        vector<float> tr_lp;
-        for (hmm_state &st : states) {
-            for (transition &t : st.tr) {
-                tr_tgt.push_back(indexOf(t.first));
-                tr_lp.push_back(t.second);
-            }
-            tr_off.push_back((int32_t)tr_tgt.size());
-            tied.push_back(acm->tied_index(st.ctx));
-        }
-        check(srx_decode_plan_create(ctx, (int)states.size(), tr_off.data(), tr_tgt.data(), tr_lp.data(), tied.data(), &dplan));
-    }
+    // the lexicon HMM's image is refreshed by update_states; a (wide) training HMM's transition scores move with every
+    // train_transition_probabilities, so its image takes them from the states on every call
+    if (!dplan || !general_topology) ensure_dplan(nullptr);
     vector<float> x;
     pack_features(fvs, x);
     Dev<float> d_x;
@@ -1261,7 +1276,9 @@ struct DeviceBatch {
 }  // namespace
 
 path hmm::viterbi(vector<featurevec *> fvs, float &prevp, float beam_width) {
-    if (general_topology) return run_graph(fvs, prevp, beam_width, 0);
+    // srx_viterbi_batch_dev keeps an utterance's states in the registers of one wavefront (512 at most); the reference has
+    // no limit (src/hmm.cpp:56-88): a wider training HMM goes through the general kernel, which gives the same score and path
+    if (general_topology || states.size() > (size_t)SRX_VITERBI_MAX_STATES) return run_graph(fvs, prevp, beam_width, 0);
     path result;
     const int64_t T = (int64_t)fvs.size();
     if (T == 0 || states.empty()) {
@@ -1347,7 +1364,8 @@ void hmm::train(vector<utterance> &ut, int iterations) {
         srx_align_plan *p = nullptr;
         ~PlanGuard() { srx_align_plan_destroy(p); }
     } plan;
-    const bool compact = g_score_path != SRX_SCORE_MFMA;
+    // the fused per-utterance scoring keeps a 256-entry state table per workgroup: wider batches take the full matrix
+    const bool compact = g_score_path != SRX_SCORE_MFMA && b.max_states <= 256;
     if (compact) {
         check(srx_align_plan_create(ctx, b.foff.data(), b.soff.data(), b.c.n_utt, &plan.p));
         check(srx_align_plan_cache_frames(plan.p, 1));   // d_x is fixed for all iterations: frame operands are built once
@@ -1382,6 +1400,23 @@ void hmm::train(vector<utterance> &ut, int iterations) {
                 check(srx_viterbi_batch_dev(ctx, &b.c, d_e.p, 1, T, 1e10f, d_path.p, d_final.p, d_status.p));
             }
             scored_version = srx_model_version(vm);
+            if (b.max_states > SRX_VITERBI_MAX_STATES) {
+                // utterances wider than srx_viterbi_batch_dev takes (status 2): one by one through the general kernel, on the
+                // same emission matrix, with the transition scores the batch holds now
+                vector<int32_t> st = d_status.get();
+                vector<float> tr;
+                for (size_t u = 0; u < ut.size(); u++) {
+                    if (st[u] != 2) continue;
+                    if (tr.empty()) tr = b.d_tr.get();
+                    hmm &h = *ut[u].hmm;
+                    vector<float> lp;
+                    for (size_t s = 0; s < h.states.size(); s++)
+                        for (size_t k = 0; k < h.states[s].tr.size(); k++) lp.push_back(tr[((size_t)b.soff[u] + s) * 3 + k]);
+                    h.ensure_dplan(lp.data());
+                    const int64_t fo[2] = {b.foff[u], b.foff[u + 1]};
+                    check(srx_viterbi_graph_dev(ctx, h.dplan, d_e.p, 1, T, fo, 1, 1e10f, 0, d_path.p, d_final.p + u, nullptr, d_status.p + u));
+                }
+            }
         }
         if (srx::verbose()) {
             vector<float> fin = d_final.get();

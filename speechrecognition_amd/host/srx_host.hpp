@@ -423,6 +423,7 @@ private:
     bool general_topology = false;       // lexicon HMM: transitions are an arbitrary list
     srx_decode_plan *dplan = nullptr;    // its device image, built on first use, refreshed by update_states
     path run_graph(std::vector<featurevec *> &fvs, float &prevp, float beam_width, int final_mode);
+    void ensure_dplan(const float *tr_lp_now);   // build the device image, or refresh its transition scores (CSR order)
 };
 
 // ------------------------------------------------------------------------------------------ utterance.hpp

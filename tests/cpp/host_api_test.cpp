@@ -144,6 +144,25 @@ int main(int argc, char **argv) {
         vector<featurevec *> few(fvs.begin(), fvs.begin() + 4);
         path none = h.viterbi(few, prevp, 1e10);   // 4 frames cannot reach state 10
         printf("no_path_len %zu\n", none.size());
+        // ---- a training HMM wider than the alignment kernel's 512 states (the reference has no limit, src/hmm.cpp:56-88):
+        // hmm::viterbi takes it through the general kernel; the second call sees the re-estimated transitions ----
+        vector<P::phone> widepron(1, P::SIL);
+        for (int i = 0; i < 598; i++) widepron.push_back((P::phone)(1 + (i * 7) % 39));
+        widepron.push_back(P::SIL);
+        hmm hw(widepron, &acm);
+        vector<featurevec *> longf;
+        for (int r = 0; r < 10; r++) longf.insert(longf.end(), fvs.begin(), fvs.end());
+        float pw = 0;
+        path wp = hw.viterbi(longf, pw, 1e10);
+        printf("wide_nstates %zu\nwide_prevp %.9g\nwide_path", hw.states.size(), (double)pw);
+        for (hmm_state *s : wp) printf(" %d", hw.indexOf(s));
+        printf("\n");
+        hw.train_transition_probabilities(wp);
+        float pw2 = 0;
+        path wp2 = hw.viterbi(longf, pw2, 1e10);
+        printf("wide_prevp2 %.9g\nwide_path2", (double)pw2);
+        for (hmm_state *s : wp2) printf(" %d", hw.indexOf(s));
+        printf("\n");
         // ---- the per-frame functions of clip.hpp / mfcc.hpp / gmm.hpp, call by call ----
         Clip fr(wav, 160 * 5, 160 * 5 + 320);           // pre-emphasised samples by now
         dump("fr_samples", wav.buf->data() + 160 * 5, 320);

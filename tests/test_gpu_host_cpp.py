@@ -119,6 +119,18 @@ def test_host_api_calls_match_oracle(oracle, tmp_path):
     want = np.concatenate([tr2[s, :ntr[s]] for s in range(11)])
     np.testing.assert_allclose(f("tr"), want, rtol=3e-6, atol=1e-7)
     assert d["no_path_len"] == ["0"]
+    # ---- 600 states: beyond srx_viterbi_batch_dev (512), through the general kernel; then again after re-estimation ----
+    phw = np.array([0] + [1 + (i * 7) % 39 for i in range(598)] + [0], np.int32)
+    ntrw, trw, _ = oracle.build_training_hmm(phw)
+    emis_long = np.tile(emis, (10, 1))
+    rw = oracle.viterbi(emis_long, phw, ntrw, trw)
+    assert d["wide_nstates"] == ["600"] and rw["status"] == 0
+    assert [int(v) for v in d["wide_path"]] == list(rw["path"])
+    assert abs(f("wide_prevp")[0] - rw["prevp"]) <= 1e-6 * abs(rw["prevp"])
+    trw2 = oracle.train_transitions(rw["path"], ntrw, trw)
+    rw2 = oracle.viterbi(emis_long, phw, ntrw, trw2)
+    assert rw2["status"] == 0 and [int(v) for v in d["wide_path2"]] == list(rw2["path"])
+    assert abs(f("wide_prevp2")[0] - rw2["prevp"]) <= 1e-6 * abs(rw2["prevp"]) and rw2["prevp"] != rw["prevp"]
     # ---- state_model::augment / operator() and hmm::update_states on the lexicon HMM (a24; src/hmm.cpp:39-51, 361-366) ----
     aug = np.array([float(v) for v in d["aug"]]).reshape(-1, 4)
     adv_path = np.exp(tr2[r["path"], 1].astype(np.float32)).astype(np.float32)[ntr[r["path"]] >= 2]
@@ -208,6 +220,86 @@ def _make_corpus(root, rng):
     return folders, samples
 
 
+def _oracle_train(oracle, feats, phone_strings, mean0, var0, w0, iters, D):
+    """hmm::train (src/hmm.cpp:249-347) with the oracle, including the acm / temp_acm ping-pong (SURVEY.md fact 12): the
+    utterance HMMs keep pointing at object O while the trainer swaps (acm, temp_acm) = (O, C), (C, O), ...  Returns the
+    trainer's acm after `iters` iterations as [mean, var, w]."""
+    allf = np.concatenate(feats)
+    O = [mean0.copy(), var0.copy(), w0.copy()]
+    Cm = [mean0.copy(), var0.copy(), w0.copy()]
+    acm, temp = O, Cm
+    hmms = [list(oracle.build_training_hmm(ph)[:2]) for ph in phone_strings]
+    gidx = [ph.astype(np.int32) for ph in phone_strings]      # tied index = phone id under NULL_CONTEXT ties
+    for _ in range(iters):
+        gids = []
+        for u, fv in enumerate(feats):
+            e = oracle.gmm_score(fv, O[0], O[1], oracle.set_wt(O[2]), D, 0)
+            r = oracle.viterbi(e, gidx[u], hmms[u][0], hmms[u][1])
+            assert r["status"] == 0
+            hmms[u][1] = oracle.train_transitions(r["path"], hmms[u][0], hmms[u][1])
+            gids.append(gidx[u][r["path"]])
+        Bm, Bv, Bw, _, _ = oracle.em_statistics(allf, np.concatenate(gids), D, acm[0], acm[1], acm[2], 0.2)
+        temp[0][...] = np.asarray(Bm, np.float64)
+        temp[1][...] = np.asarray(Bv, np.float64)
+        temp[2][...] = Bw
+        acm, temp = temp, acm
+    return acm
+
+
+def test_headless_driver_trains_on_an_utterance_wider_than_the_alignment_kernel(oracle, tmp_path):
+    """hmm::train with a 600-phone utterance in the corpus (the reference has no state limit, src/hmm.cpp:56-88; the
+    alignment kernel holds 512): that utterance is aligned by the general kernel inside the batch loop, with the batch's
+    current transition scores, and the trained model matches the oracle's at the bars of the faithful statistics."""
+    assert os.path.exists(SRX), "run __graft_entry__.build() first"
+    rng = np.random.default_rng(12)
+    root = str(tmp_path / "vox") + "/"
+    fo = "spk1-20260101-aaa/"
+    for sub in ("etc", "wav", "mfc"):
+        os.makedirs(os.path.join(root, fo, sub))
+    lens = {"wide": 150000, "b": 20000, "c": 26000}
+    for k, (name, L) in enumerate(sorted(lens.items())):
+        _write_wav(os.path.join(root, fo, "wav", name + ".wav"), synth.utterance_audio(300 + k, L))
+    open(os.path.join(root, fo, "etc", "PROMPTS"), "w").write("".join("%smfc/%s X\n" % (fo, n) for n in sorted(lens)))
+    for lst in ("_list", "_train"):
+        open(os.path.join(root, lst), "w").write(fo + "\n")
+    _run([SRX, "--mode", "mfcc", "--voxforge", root])
+    phones = {"wide": np.array([0] + [1 + (i * 11) % 39 for i in range(598)] + [0], np.int32),
+              "b": synth.phone_string(rng, n_words=3), "c": synth.phone_string(rng, n_words=3)}
+    open(os.path.join(root, fo, "etc", "PHONES"), "w").write(
+        "".join("%smfc/%s %s\n" % (fo, n, " ".join(PHONE_NAMES[p] for p in phones[n])) for n in sorted(lens)))
+    order = sorted(lens)
+    feats = [oracle.read_features(_read_mfc(os.path.join(root, fo, "mfc", n)), 2) for n in order]
+    assert len(feats[2]) > 700        # "wide" sorts last; enough frames for its 600 states
+    allf = np.concatenate(feats)
+    G, D = 40, 13
+    mu, sd = allf[:, :D].mean(0), allf[:, :D].std(0)
+    mean0 = (mu + sd * rng.standard_normal((G, 1, D)) * 0.7).astype(np.float64)
+    var0 = (sd ** 2 * rng.uniform(0.8, 1.2, (G, 1, D))).astype(np.float64)
+    w0 = np.ones((G, 1), np.float32)
+    with open(root + "init.txt", "w") as f:
+        f.write("srx-model %d 1 %d\n" % (G, D))
+        for g in range(G):
+            f.write("state 0 %d 0\nw 1\nmean %s\nvar %s\n" % (g, " ".join(repr(float(v)) for v in mean0[g, 0]),
+                                                           " ".join(repr(float(v)) for v in var0[g, 0])))
+    iters = 2
+    env = {"SRX_SCORE_PATH": "exact", "SRX_EM_PATH": "faithful"}
+    _run([SRX, "--mode", "train", "--voxforge", root, "--iters", str(iters), "--model", root + "init.txt", "--out", root + "trained.txt"], env)
+    acm = _oracle_train(oracle, feats, [phones[n] for n in order], mean0, var0, w0, iters, D)
+    got = open(root + "trained.txt").read().split("\n")
+    gm = np.array([[float(v) for v in ln.split()[1:]] for ln in got if ln.startswith("mean")])
+    gv = np.array([[float(v) for v in ln.split()[1:]] for ln in got if ln.startswith("var")])
+    rm, rv = acm[0][:, 0, :], acm[1][:, 0, :]
+    assert np.array_equal(np.isnan(gm), np.isnan(rm))
+    ok = ~np.isnan(rm)
+    assert ok.sum() == 13 * 40        # the wide utterance visits every phone
+    np.testing.assert_allclose(gm[ok], rm[ok], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gv[ok], rv[ok], rtol=1e-7, atol=1e-9)
+    # alignment of the wide utterance under the trained model: hmm::viterbi's own fallback
+    a = _run([SRX, "--mode", "align", "--voxforge", root, "--model", root + "trained.txt"], env)
+    rows = [ln.split() for ln in a.splitlines() if ln and ln[0].isdigit()]
+    assert len(rows) == 3 and len(rows[2]) == 2 + len(feats[2]) and int(rows[2][-1]) == 599
+
+
 def test_headless_driver_mfcc_train_align(oracle, tmp_path):
     assert os.path.exists(SRX), "run __graft_entry__.build() first"
     rng = np.random.default_rng(3)
@@ -257,24 +349,8 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
           root + "trained.txt"], env)
     # ---- the same three iterations with the oracle, including the acm / temp_acm ping-pong:
     # the utterance HMMs keep pointing at object O while the trainer swaps (acm, temp_acm) = (O, C), (C, O), ...
-    O = [mean0.copy(), var0.copy(), w0.copy()]
-    Cm = [mean0.copy(), var0.copy(), w0.copy()]
-    acm, temp = O, Cm
-    hmms = [list(oracle.build_training_hmm(phones[k])[:2]) for k in order]
+    acm = _oracle_train(oracle, feats, [phones[k] for k in order], mean0, var0, w0, iters, D)
     gidx = [phones[k].astype(np.int32) for k in order]      # tied index = phone id under NULL_CONTEXT ties
-    for _ in range(iters):
-        gids = []
-        for u, fv in enumerate(feats):
-            e = oracle.gmm_score(fv, O[0], O[1], oracle.set_wt(O[2]), D, 0)
-            r = oracle.viterbi(e, gidx[u], hmms[u][0], hmms[u][1])
-            assert r["status"] == 0
-            hmms[u][1] = oracle.train_transitions(r["path"], hmms[u][0], hmms[u][1])
-            gids.append(gidx[u][r["path"]])
-        Bm, Bv, Bw, _, _ = oracle.em_statistics(allf, np.concatenate(gids), D, acm[0], acm[1], acm[2], 0.2)
-        temp[0][...] = np.asarray(Bm, np.float64)
-        temp[1][...] = np.asarray(Bv, np.float64)
-        temp[2][...] = Bw
-        acm, temp = temp, acm
     got = open(root + "trained.txt").read().split("\n")
     gm = np.array([[float(v) for v in ln.split()[1:]] for ln in got if ln.startswith("mean")])
     gv = np.array([[float(v) for v in ln.split()[1:]] for ln in got if ln.startswith("var")])

@@ -103,6 +103,69 @@ def test_viterbi_mixed_widths_in_one_batch(ctx, oracle):
     hb.close()
 
 
+def test_viterbi_wide_utterances_eight_states_per_lane(ctx, oracle):
+    """More than 256 states per utterance (the reference has no limit, src/hmm.cpp:56-88): up to
+    SRX_VITERBI_MAX_STATES = 512 the alignment kernel takes eight states per lane, bit-exact in every layout and with a
+    beam; a still wider utterance gets status 2 there and the same score and path from the general kernel
+    (srx_viterbi_graph_dev), which is what hmm::viterbi / hmm::train of the host layer fall back to."""
+    rng = np.random.default_rng(88)
+    G = 45
+    sizes = [300, 512, 257, 40, 130, 600]
+    ntrs, trs, tieds, Ts, phs = [], [], [], [], []
+    for S in sizes:
+        ph = rng.integers(1, 40, S).astype(np.int32)
+        ph[rng.random(S) < 0.12] = 0           # optional silences: three-transition states
+        ph[0] = ph[-1] = 0
+        ntr, tr, _ = host.build_training_hmm(ph)
+        phs.append(ph); ntrs.append(ntr); trs.append(tr)
+        tieds.append(rng.integers(0, G, S).astype(np.int32))
+        Ts.append(S + int(rng.integers(30, 200)))
+    fo = np.zeros(len(sizes) + 1, np.int64)
+    fo[1:] = np.cumsum(Ts)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 20).astype(np.float32)
+    n_ok = len(sizes) - 1
+    # the five that fit: every layout, and a beam
+    _check(ctx, oracle, ntrs[:n_ok], trs[:n_ok], tieds[:n_ok], fo[:n_ok + 1], emis)
+    _check(ctx, oracle, ntrs[:n_ok], trs[:n_ok], tieds[:n_ok], fo[:n_ok + 1], emis, state_major=True)
+    _check(ctx, oracle, ntrs[:n_ok], trs[:n_ok], tieds[:n_ok], fo[:n_ok + 1], emis, state_major="aligned")
+    _check(ctx, oracle, ntrs[:n_ok], trs[:n_ok], tieds[:n_ok], fo[:n_ok + 1], emis, beam=150.0, state_major="aligned")
+    # all six: the 600-state utterance is refused (status 2), the others are as before
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    assert hb.max_states == 600
+    emis_d = ctx.array(emis)
+    path_d, final_d, status_d = hb.viterbi(emis_d, G, 1, 1e10)
+    ctx.sync()
+    path, final, status = path_d.get(), final_d.get(), status_d.get()
+    assert list(status) == [0, 0, 0, 0, 0, 2]
+    for u in range(n_ok):
+        r = oracle.viterbi(emis[fo[u]:fo[u + 1]], tieds[u], ntrs[u], trs[u], 1e10, 0)
+        assert final[u].tobytes() == r["final"].tobytes() and np.array_equal(path[fo[u]:fo[u + 1]], r["path"]), u
+    # ... and goes through the general kernel on the same emission matrix
+    u = n_ok
+    S = sizes[u]
+    off = np.zeros(S + 1, np.int32)
+    off[1:] = np.cumsum(ntrs[u])
+    tgt = np.concatenate([np.arange(s, s + ntrs[u][s]) for s in range(S)]).astype(np.int32)
+    lp = np.concatenate([trs[u][s, :ntrs[u][s]] for s in range(S)]).astype(np.float32)
+    g = host.GraphHmm(ctx, off, tgt, lp, tieds[u])
+    r = oracle.viterbi(emis[fo[u]:fo[u + 1]], tieds[u], ntrs[u], trs[u], 1e10, 0)
+    for sweep in (host.DECODE_DENSE, host.DECODE_FRONTIER):
+        g.set_sweep(sweep)
+        p, f, fs, st = g.viterbi(emis_d, G, 1, fo[u:u + 2], 1e10, 0)
+        assert st[0] == 0 == r["status"] and f[0].tobytes() == r["final"].tobytes()
+        assert np.array_equal(p[fo[u]:fo[u + 1]], r["path"])
+    g.close()
+    # train_transition_probabilities on the wide batch (its per-state counters are sized by max_states)
+    hb.train_transition_probabilities(path_d, status_d)
+    ctx.sync()
+    got, so = hb.trlogp(), hb.state_off
+    for u in range(n_ok):
+        want = oracle.train_transitions(path[fo[u]:fo[u + 1]], ntrs[u], trs[u])
+        np.testing.assert_allclose(got[so[u]:so[u + 1]], want, rtol=3e-6, atol=1e-7)
+    np.testing.assert_array_equal(got[so[n_ok]:so[n_ok + 1]], trs[n_ok])      # status 2: untouched
+    hb.close()
+
+
 def test_viterbi_positive_scores_and_short_T(ctx, oracle):
     """Log-densities are routinely positive (log(2/pi) constant, src/gmm.cpp:43); T barely reaching the
     last state, T too short (NO PATH, src/hmm.cpp:212-215), T = 1."""
