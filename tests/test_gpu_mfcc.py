@@ -1,8 +1,9 @@
 """Parity of the HIP MFCC / feature path against the CPU oracle (oracle/srx_oracle.c).
 
 Tolerances (north_star: "MFCCs ... within 1e-4 relative"): cepstra of one frame are compared against the
-frame's own cepstral scale, |a-b| <= 1e-4 * max_j |ref_j|; element-wise relative error is meaningless for
-the DCT's near-cancelling higher coefficients.  Integer-like / pure-f32 stages are bit-exact."""
+frame's own cepstral scale, |a-b| <= 1e-4 * max_j |ref_j|, and element-wise against 1e-4 |c_j| plus the propagated
+rounding of the reference's own log(x + 1) (test_mfcc_elementwise_bound: derived, zero exceptions).  Integer-like /
+pure-f32 stages are bit-exact."""
 import numpy as np
 import pytest
 
@@ -238,6 +239,42 @@ def test_partial_dft_mirror_branch(ctx, oracle):
     spec, fo = plan.partial_dft(x, np.array([0, 1000], np.int64))
     ref = np.stack([oracle.partial_dft(x[f * hop:f * hop + wl], wl, bm) for f in range(int(fo[1]))])
     assert (np.abs(spec - ref) / np.abs(ref).max(axis=1, keepdims=True)).max() <= 1e-4
+    plan.close()
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("wl", [320, 400])
+def test_mfcc_elementwise_bound(ctx, oracle, wl, path, normalize):
+    """north_star's "within 1e-4 relative" taken ELEMENT-WISE, as a bound with zero exceptions:
+
+        |dc_j|  <=  1e-4 |c_j|  +  K 2^-24 sum_i |cos(j i pi / n)|,      K = 2.
+
+    Where the absolute term comes from: c_j = sum_i lf_i cos(j i pi / n) (src/mfcc.cpp:205-214) with lf_i = log(x_i + 1) of the
+    filterbank output x_i (src/utils.hpp:55-60), and `x_i + 1` is ROUNDED TO F32 before the logarithm.  For the normalised
+    corpus x_i ~ 1e-2, so the sum lies in [1, 2) where one f32 step is 2^-23 = 2 * 2^-24: a filter output that arrives with
+    any deviation at all (another summation order in the transform is enough) can land `x_i + 1` on the neighbouring float,
+    and log moves by that step / (1 + x_i) <= 2^-23 -- per filter output, whatever the size of lf_i or c_j.  The DCT carries
+    it into every cepstrum with weight |cos|: K = 2, one unit in the last place of 1.0 per filter output.  A cepstrum that
+    nearly cancels (|c_j| ~ 1e-6 against lf_i ~ 1e-2) therefore cannot be held to 1e-4 of ITSELF by any evaluation order but
+    the reference's own; it can be, and is, held to this bound.  Measured need (tools/mfcc_bound_probe.py,
+    profiles/r03_mfcc_elementwise_bound.json): K = 0.05-0.21 over the three paths, both windows, normalised or not -- the
+    roundings do not all flip, and not all the same way.  Without normalisation x_i >> 1, lf_i ~ 10 and the relative term
+    carries the comparison."""
+    lens = [16000, 23456, 5000]
+    off = np.zeros(len(lens) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    x = np.concatenate([synth.utterance_audio(100 + i, n) for i, n in enumerate(lens)])
+    x[:16000] = (0.5 * np.random.default_rng(1).standard_normal(16000)).clip(-1, 1)
+    nf = 48
+    fb, _ = host.mel_filterbank(7200, nf, wl, 16000)
+    plan = host.MfccPlan(ctx, host.mfcc_config(wl, 160, normalize=normalize), fb, path)
+    got, _ = plan.write_features(x, off)
+    ref = _oracle_batch(oracle, x, off, wl, 160, fb, normalize=normalize)
+    cosabs = np.abs(np.cos(np.arange(13)[:, None] * np.arange(nf)[None, :] * np.pi / nf)).sum(axis=1)
+    bound = 1e-4 * np.abs(ref) + 2.0 * 2.0 ** -24 * cosabs[None, :]
+    d = np.abs(got.astype(np.float64) - ref)
+    assert (d <= bound).all(), (float((d / bound).max()), int((d > bound).sum()))
     plan.close()
 
 
