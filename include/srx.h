@@ -283,8 +283,9 @@ typedef struct {
  * emis[t*stride_t + tied[s]*stride_g] = (*acm)(*fvs[t], states[s].ctx), t counted over the whole
  * batch (the strides of srx_gmm_score_dev).  Outputs: path[total_frames]
  * (state index within the utterance), final_logp[n_utt] (= curr[best]), status[n_utt]
- * (0 ok, 1 "NO PATH": path/final untouched; 2: the utterance has more than SRX_VITERBI_MAX_STATES = 512 states, or more
- * than the 64 / 128 / 256 / 512 that hmm->max_states sized the launch for: nothing computed -- take it through
+ * (0 ok, 1 "NO PATH": path/final untouched; 2: the utterance has no state at all, more than SRX_VITERBI_MAX_STATES = 512
+ * states, or more than the 64 / 128 / 256 / 512 that hmm->max_states sized the launch for (a caller bug): nothing computed.
+ * Status 2 is a refusal, not a property of the audio: take a wide utterance through
  * srx_viterbi_graph_dev, which has no limit and gives the same score and path; hmm::viterbi / hmm::train of the host layer
  * do.  The reference has no limit, src/hmm.cpp:56-88).
  * prevp of the reference = final_logp / T.
@@ -464,7 +465,10 @@ int srx_em_fused_finish_dev(srx_ctx *ctx, srx_model *A, srx_model *B, const doub
  * ranks out of band (file, environment, the launcher's store); srx_comm_create joins (collective over the ranks; one
  * GPU per rank).  srx_comm_create_host is a REHEARSAL transport for ranks that share one GPU, which RCCL refuses:
  * buffers cross a POSIX shared-memory segment `shm_name` ("/name") and are summed on the host in rank order.  It exists
- * so that multi-rank control flow can be tested on a one-GPU box; it is not a data path. */
+ * so that multi-rank control flow can be tested on a one-GPU box; it is not a data path.  `shm_name` must be unique to the
+ * launch (the host layer appends its launch nonce): rank 0 removes and recreates the name, but a rank that arrives first
+ * could otherwise join a segment a crashed launch left behind.  A copy that fails inside an all-reduce fails the call on
+ * EVERY rank (no rank is left waiting) and the communicator stays unusable. */
 typedef struct srx_comm srx_comm;
 enum { SRX_COMM_ID_BYTES = 128 };
 int srx_comm_unique_id(void *id_out);

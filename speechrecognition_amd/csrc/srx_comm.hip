@@ -64,6 +64,7 @@ int rccl_load(srx_ctx *ctx) {
 // ---- host rehearsal transport ----
 struct ShmHeader {
     std::atomic<int> ready;
+    std::atomic<int> abort;   // a rank failed inside an all-reduce: every rank leaves the call with an error, no rank skips a barrier
     int world;
     size_t slot_bytes;
     pthread_barrier_t barrier;
@@ -188,6 +189,7 @@ extern "C" int srx_comm_create_host(srx_ctx *ctx, int rank, int world, const cha
         pthread_barrierattr_destroy(&at);
         c->hdr->world = world;
         c->hdr->slot_bytes = kSlotBytes;
+        c->hdr->abort.store(0, std::memory_order_relaxed);
         c->hdr->ready.store(1, std::memory_order_release);
     } else {
         for (int tries = 0; tries < 3000 && c->hdr->ready.load(std::memory_order_acquire) != 1; tries++)
@@ -248,18 +250,37 @@ int allreduce(srx_comm *c, T *buf, int64_t n, int nccl_type, const char *what) {
         if (e != 0) return srx_fail(ctx, SRX_ERR_DEVICE, "%s: ncclAllReduce: %s", what, g_rccl.GetErrorString(e));
         return SRX_OK;
     }
+    // Every rank passes the same barriers whatever happens to it (n is the same on every rank): a failed copy raises the
+    // segment's abort flag instead of returning, so that no peer is left waiting in a barrier; the flag is seen by everyone
+    // behind the next barrier and the call fails on every rank.
     const size_t per = kSlotBytes / sizeof(T);
+    hipError_t first_err = hipSuccess;
+    auto note = [&](hipError_t e) {
+        if (e != hipSuccess) {
+            if (first_err == hipSuccess) first_err = e;
+            c->hdr->abort.store(1, std::memory_order_release);
+        }
+    };
     for (int64_t o = 0; o < n; o += (int64_t)per) {
         const size_t cnt = (size_t)((n - o) < (int64_t)per ? (n - o) : (int64_t)per);
         unsigned char *mine = c->slots + (size_t)c->rank * kSlotBytes;
-        SRX_HIP(ctx, hipMemcpyAsync(mine, buf + o, cnt * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const bool live = c->hdr->abort.load(std::memory_order_acquire) == 0;
+        if (live) {
+            note(hipMemcpyAsync(mine, buf + o, cnt * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+            note(hipStreamSynchronize(ctx->stream));
+        }
         pthread_barrier_wait(&c->hdr->barrier);
-        reduce_slots<T, MAX>(c->slots, c->world, kSlotBytes, cnt, reinterpret_cast<T *>(c->stage.data()));
+        const bool ok = c->hdr->abort.load(std::memory_order_acquire) == 0;
+        if (ok) reduce_slots<T, MAX>(c->slots, c->world, kSlotBytes, cnt, reinterpret_cast<T *>(c->stage.data()));
         pthread_barrier_wait(&c->hdr->barrier);   // everybody has read every slot before anyone overwrites its own
-        SRX_HIP(ctx, hipMemcpyAsync(buf + o, c->stage.data(), cnt * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ok) {
+            note(hipMemcpyAsync(buf + o, c->stage.data(), cnt * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+            note(hipStreamSynchronize(ctx->stream));
+        }
     }
+    if (first_err != hipSuccess) return srx_fail(ctx, SRX_ERR_DEVICE, "%s: %s", what, hipGetErrorString(first_err));
+    if (c->hdr->abort.load(std::memory_order_acquire) != 0)
+        return srx_fail(ctx, SRX_ERR_DEVICE, "%s: another rank failed inside an all-reduce; the communicator is unusable", what);
     return SRX_OK;
 }
 }  // namespace

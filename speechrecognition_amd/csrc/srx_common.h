@@ -146,6 +146,7 @@ struct srx_model {
     size_t packed16s_bytes = 0;
     uint64_t packed16s_version = 0;
     int packed16s_mode = -1;
+    uint64_t packed16s_epoch = 0;  // colstats_epoch the per-state table was built with
     float *colstats = nullptr;     // [3][D]: centre, column scale s_d, 1/s_d in use; followed by [3][D] of the current model (candidate)
     uint64_t colstats_epoch = 0;   // bumped whenever the values in use change (frame operands built with them are then stale)
     int *flag16 = nullptr;         // device flag: some coefficient does not fit f16

@@ -174,7 +174,10 @@ __global__ __launch_bounds__(256) void k_pack16_state(const double *__restrict__
 static int ensure_packed16s(srx_ctx *ctx, srx_model *m, int mix_mode, int KS) {
     int rc = ensure_packed16(ctx, m, mix_mode, KS);   // column statistics and the "fits f16" verdict
     if (rc != SRX_OK) return rc;
-    if (m->packed16s_version == m->version && m->packed16s_mode == mix_mode && m->packed16s) return SRX_OK;
+    // the table holds coefficients scaled with the centre / scale vector in force when it was built: a replaced vector (a dense
+    // score in the other mix mode can adopt a new one without any change of the model's version) makes it stale
+    if (m->packed16s_version == m->version && m->packed16s_mode == mix_mode && m->packed16s_epoch == m->colstats_epoch && m->packed16s)
+        return SRX_OK;
     const int Muse = mix_mode == SRX_MIX_COMPONENT0 ? 1 : m->M;
     const int MP = padded_components16(Muse);
     const int64_t n = (int64_t)m->G * 2 * KS * MP * 2;
@@ -194,6 +197,7 @@ static int ensure_packed16s(srx_ctx *ctx, srx_model *m, int mix_mode, int KS) {
     SRX_LAUNCH_CHECK(ctx);
     m->packed16s_version = m->version;
     m->packed16s_mode = mix_mode;
+    m->packed16s_epoch = m->colstats_epoch;
     return SRX_OK;
 }
 

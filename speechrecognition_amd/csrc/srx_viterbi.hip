@@ -365,7 +365,9 @@ __device__ __forceinline__ bool viterbi_utt(const int u, const int64_t *__restri
     if (!BEAM) {
         bool bad = false;
 #pragma unroll
-        for (int q = 0; q < SPL; q++) bad |= (lane * SPL + q < S) && !(mx[q] < 2.5e9f);   // also true for NaN
+        // fmaxf drops a NaN operand, so a NaN never reaches mx; but a NaN delta is sticky (every comparison against it is false
+        // and the state keeps its own NaN candidate), so the final deltas show whether one occurred
+        for (int q = 0; q < SPL; q++) bad |= (lane * SPL + q < S) && (!(mx[q] < 2.5e9f) || dl[q] != dl[q]);
         if (__any(bad)) return true;
     }
     // ---- end condition: the path must end in the last state (src/hmm.cpp:210-215) ----

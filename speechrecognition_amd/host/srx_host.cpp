@@ -195,7 +195,11 @@ void init_distributed() {
     srx_ctx *ctx = context();
     int rc;
     if (const char *shm = std::getenv("SRX_COMM_SHM")) {
-        rc = srx_comm_create_host(ctx, g_rank, g_world, shm, &g_comm);
+        // the segment's name carries the launch nonce: a segment left behind by a crashed launch has another name and cannot
+        // be joined by mistake (the same caveat as for SRX_COMM_FILE: launches with identical rendezvous values need SRX_COMM_NONCE)
+        char name[256];
+        snprintf(name, sizeof name, "%s_%016llx", shm, (unsigned long long)launch_nonce());
+        rc = srx_comm_create_host(ctx, g_rank, g_world, name, &g_comm);
     } else {
         const char *file = std::getenv("SRX_COMM_FILE");
         if (!file) throw srx_error(SRX_ERR_INVALID, "WORLD_SIZE > 1 needs SRX_COMM_FILE (where rank 0 publishes the RCCL id) or SRX_COMM_SHM");

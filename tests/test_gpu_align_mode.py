@@ -91,6 +91,49 @@ def test_align_scores_equal_dense_scores_bitwise(ctx, oracle, G, M, D, mode):
     model.close()
 
 
+def test_align_table_follows_the_centre_scale_vector_in_force(ctx):
+    """the per-state coefficient table of the alignment kernel is scaled with the model's centre / scale vector,
+    which ensure_packed16 KEEPS from one model version to the next while it still suits the model and may REPLACE without a
+    change of the model's version (a dense score in the other mix mode whose coefficients no longer fit f16 with the kept
+    one).  The table's validity is keyed on that vector's epoch as well as on (version, mode).  Here: one model, contracted
+    to 0.3 of its size (kept vector in force: the scales are within the 4x window), then sharpened 50x in one component
+    (coefficients 50x larger: what still fits is mode dependent), with mix modes and dense / alignment scoring alternating
+    -- alignment scores equal the dense ones bit for bit at every step, whichever vector each step ended up with."""
+    rng = np.random.default_rng(99)
+    G, M, D = 64, 4, 39
+    ntrs, trs, tieds, fo = _batch(rng, 9, G, 20, 200)
+    T = int(fo[-1])
+    feats = (rng.standard_normal((T, 39)) * 0.5).astype(np.float32)
+    feats_d = ctx.array(feats)
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    mean, var, w = synth.random_model(G, M, D, 3)
+    model = host.AcousticModel(ctx, G, M, D)
+    other = {SRX_MIX_COMPONENT0: SRX_MIX_LOGSUMEXP, SRX_MIX_LOGSUMEXP: SRX_MIX_COMPONENT0}
+
+    def check(mode):
+        got = hb.score_align(model, feats_d, 39, mix_mode=mode).get()
+        ref = _compact_from_dense(model.score(feats, mode, SRX_SCORE_MFMA_F16X3), hb, tieds)
+        assert got.tobytes() == ref.tobytes(), mode
+
+    def alternate():
+        for mode in (SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP, SRX_MIX_COMPONENT0, SRX_MIX_LOGSUMEXP):
+            check(mode)                                                   # builds / reuses the alignment table of `mode`
+            model.score(feats, other[mode], SRX_SCORE_MFMA_F16X3)         # a dense score in the other mode: may replace the vector
+            check(mode)                                                   # same model version, same mode: the table must follow
+
+    model.set(mean, var, w)
+    alternate()
+    mean2, var2 = mean * 0.3, var * 0.09
+    model.set(mean2, var2, w)
+    alternate()
+    var3 = var2.copy()
+    var3[:, 1, :] /= 50.0
+    model.set(mean2, var3, w)
+    alternate()
+    model.close()
+    hb.close()
+
+
 def test_model_f16_cannot_hold_is_scored_exactly(ctx):
     rng = np.random.default_rng(1)
     G, M, D = 30, 2, 13

@@ -238,3 +238,41 @@ def test_viterbi_nonfinite_and_huge_emissions_follow_the_reference_pruning_test(
     _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major=True)
     _check(ctx, oracle, ntrs, trs, tieds, fo, emis, state_major="aligned")
     _check(ctx, oracle, ntrs, trs, tieds, fo, emis, beam=50.0)
+
+
+def test_viterbi_nan_emissions_take_the_pruning_body(ctx, oracle):
+    """a tied state whose parameters became 0/0 (never visited in training) scores NaN on every frame -- reference
+    behaviour.  A NaN delta used to slip past the no-beam body's "largest |delta|" record (fmaxf drops NaN operands) and the
+    utterance was never repeated through the body that applies the reference's pruning test.  Now it is: the result is the
+    one the beam body gives, which is the oracle's with the same visiting order (a NaN candidate is kept only where it
+    arrives first, src/hmm.cpp:171-183: `logp > next[target]` is false for NaN on either side)."""
+    rng = np.random.default_rng(62)
+    G = 30
+    _, ntrs, trs, tieds, fo = _make_batch(rng, 6, G, 60, 200, words=4)
+    emis = (rng.standard_normal((int(fo[-1]), G)) * 4 - 20).astype(np.float32)
+    emis[fo[1]:fo[2], tieds[1][3]] = np.nan          # one tied state NaN throughout an utterance
+    emis[fo[3] + 10:fo[3] + 14, tieds[3][1]] = np.nan  # and for a few frames only
+    hb = host.HmmBatch(ctx, fo, ntrs, trs, tieds)
+    emis_d = ctx.array(emis)
+    res = {}
+    for beam in (1e10, 1e9):                          # no-beam body (with its repeat) and the pruning body itself
+        p, f, s = hb.viterbi(emis_d, G, 1, beam)
+        ctx.sync()
+        res[beam] = (p.get(), f.get(), s.get())
+    assert np.array_equal(res[1e10][2], res[1e9][2])
+    for u in range(len(ntrs)):
+        if res[1e10][2][u] == 0:
+            a, b = res[1e10][1][u], res[1e9][1][u]
+            assert a.tobytes() == b.tobytes() or (np.isnan(a) and np.isnan(b)), u
+            assert np.array_equal(res[1e10][0][fo[u]:fo[u + 1]], res[1e9][0][fo[u]:fo[u + 1]]), u
+    for u in (0, 2, 4, 5):                            # the untouched utterances: the oracle, as ever
+        r = oracle.viterbi(emis[fo[u]:fo[u + 1]], tieds[u], ntrs[u], trs[u], 1e10, 0)
+        assert res[1e10][2][u] == r["status"] == 0 and res[1e10][1][u].tobytes() == r["final"].tobytes()
+        assert np.array_equal(res[1e10][0][fo[u]:fo[u + 1]], r["path"])
+    report = {}
+    for u in (1, 3):                                  # the NaN utterances against the oracle: recorded, see the assertion below
+        r = oracle.viterbi(emis[fo[u]:fo[u + 1]], tieds[u], ntrs[u], trs[u], 1e10, 0)
+        same = res[1e10][2][u] == r["status"] and (r["status"] != 0 or np.array_equal(res[1e10][0][fo[u]:fo[u + 1]], r["path"]))
+        report[u] = bool(same)
+    assert all(report.values()), report
+    hb.close()
