@@ -14,6 +14,8 @@
 // reading logp and the feature rows once.
 #include "srx_common.h"
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 128-bit load from a 4-byte aligned address
+
 // exp(y) in f64 for the zeta of the accumulation passes (y = logp - shift: at most a little above 0, down to -inf).
 // n = rint(y / ln 2), r = y - n ln 2 in two parts, degree-13 Taylor polynomial on |r| <= 0.347 (remainder 4e-18),
 // v_ldexp_f64 for the scale (gradual underflow like exp()).  18 f64 instructions, no branches; checked in the
@@ -508,8 +510,9 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
                                                     int D, const double *__restrict__ meanA, const double *__restrict__ rvarA,
                                                     const float *__restrict__ weight, const float *__restrict__ logp_in,
                                                     const float *__restrict__ shift_in, double *__restrict__ partial) {
-    constexpr int H = 8 * NCT, K = 2 * H, NV = 2 * NCT;   // NV: values of a frame row per lane (columns 4 kk + kq)
-    __shared__ double xs[16][H + 1];
+    constexpr int H = 8 * NCT, K = 2 * H, NV = 2 * NCT;   // NV: values of a frame row per lane: columns NV kq + kk, a contiguous slice
+    // (the k index of an MFMA may be permuted freely as long as both operands agree: k-chunk kk, slot kq <-> column NV kq + kk)
+    __shared__ double xs[16][K + 1];   // a tile's centred rows: [x - c | 1 | 0.. ] in columns 0 .. H-1, their squares in H .. 2H-1
     __shared__ double cs[H];
     const int item = blockIdx.x;
     if (item >= item_start[G]) return;
@@ -535,10 +538,10 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
     __syncthreads();
     double cen[NV];   // centre of the columns this lane loads
 #pragma unroll
-    for (int kk = 0; kk < NV; kk++) cen[kk] = cs[4 * kk + kq];
+    for (int kk = 0; kk < NV; kk++) cen[kk] = cs[NV * kq + kk];
     const double wm = m < M ? (double)weight[(size_t)g * M + m] : 0.0;
     const double sm = (!LOGP_MFMA && m < M) ? (double)shift_in[(size_t)g * M + m] : 0.0;
-    // W^T as B operand of the first product: lane (k = kq, column m) holds W[m][4 kk + kq] for the 2 NV k-chunks
+    // W^T as B operand of the first product: lane (k = kq, column m) holds W[m][NV kq + kk] for the 2 NV k-chunks
     double wreg[LOGP_MFMA ? 2 * NV : 1];
     if (LOGP_MFMA) {
         double k0 = 0.0;
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
             }
 #pragma unroll
         for (int kk = 0; kk < NV; kk++) {
-            const int e = 4 * kk + kq;
+            const int e = NV * kq + kk;
             double lin = 0.0, quad = 0.0;
             if (m < M && e < D) {
                 const double rv = rvarA[((size_t)g * M + m) * D + e];
@@ -562,35 +565,53 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
         }
     }
     f64x4 acc[NCT];
+    const int bcol = fl < 8 ? fl : H + (fl & 7);
 #pragma unroll
     for (int c = 0; c < NCT; c++) acc[c] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const int ntiles = (nfr + 15) >> 4;
-    // frame row of tile t for this lane: frame 16 t + fl, columns 4 kk + kq
+    // frame row of tile t for this lane: frame 16 t + fl, columns NV kq .. NV kq + NV - 1: 128-bit loads (4-byte aligned
+    // addresses are enough for them), four lanes cover a row's 156 bytes back to back
     auto load_ord = [&](int t) -> int {
         const int f = 16 * t + fl;
         return f < nfr ? order[p0 + f] : -1;
     };
+    const int e0 = NV * kq;
+    const int nvalid = D - e0 < NV ? (D - e0 < 0 ? 0 : D - e0) : NV;   // columns of this lane's slice that exist in a row
     auto load_row = [&](int o, float (&x)[NV]) __attribute__((always_inline)) {
+        const float *row = feats + (int64_t)(o >= 0 ? o : 0) * ld + e0;
 #pragma unroll
-        for (int kk = 0; kk < NV; kk++) {
-            const int e = 4 * kk + kq;
-            x[kk] = (o >= 0 && e < D) ? feats[(int64_t)o * ld + e] : 0.0f;
+        for (int q4 = 0; q4 < NV; q4 += 4) {
+            if (q4 + 4 <= NV && nvalid >= q4 + 4) {
+                const f4u v = *reinterpret_cast<const f4u *>(row + q4);
+                x[q4] = v.x; x[q4 + 1] = v.y; x[q4 + 2] = v.z; x[q4 + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int kk = q4; kk < (q4 + 4 < NV ? q4 + 4 : NV); kk++) x[kk] = kk < nvalid ? row[kk] : 0.0f;
+            }
+        }
+        if (o < 0) {
+#pragma unroll
+            for (int kk = 0; kk < NV; kk++) x[kk] = 0.0f;
         }
     };
-    int ord_cur = load_ord(0), ord_nxt = ntiles > 1 ? load_ord(1) : -1;
-    float xr[NV];
+    // rows travel two tiles ahead of the arithmetic, frame indices three
+    int ord_b = ntiles > 1 ? load_ord(1) : -1, ord_c = ntiles > 2 ? load_ord(2) : -1;
+    int ord_cur = load_ord(0);
+    float xr[NV], xr2[NV];
     load_row(ord_cur, xr);
+    load_row(ord_b, xr2);
     for (int t = 0; t < ntiles; t++) {
         // ---- this lane's slice of the tile: centred values (= its A operand of the first product), also into LDS ----
         double v1[NV];
 #pragma unroll
         for (int kk = 0; kk < NV; kk++) {
-            const int e = 4 * kk + kq;
+            const int e = NV * kq + kk;
             double v = (double)xr[kk] - cen[kk];
             if (e == D) v = 1.0;
             if (e > D) v = 0.0;
             v1[kk] = v;
             xs[fl][e] = v;
+            xs[fl][H + e] = v * v;
         }
         float lpin[4];
         if (!LOGP_MFMA) {
@@ -601,11 +622,13 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
             }
         }
         __syncthreads();
-        // ---- the next tile's loads fly under this tile's arithmetic ----
-        const int ord_use = ord_nxt;
-        if (t + 1 < ntiles) load_row(ord_use, xr);
-        ord_cur = ord_use;
-        ord_nxt = t + 2 < ntiles ? load_ord(t + 2) : -1;
+        // ---- the loads of tile t + 2 fly under this tile's and the next tile's arithmetic ----
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) xr[kk] = xr2[kk];
+        if (!LOGP_MFMA) ord_cur = ord_b;
+        ord_b = ord_c;
+        load_row(ord_b, xr2);          // (-1 past the item's end: zeros)
+        ord_c = t + 3 < ntiles ? load_ord(t + 3) : -1;
         // ---- zeta for frames kq + 4r, component m ----
         double z[4];
         if (LOGP_MFMA) {
@@ -631,8 +654,7 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
         for (int c = 0; c < NCT; c++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const double x = xs[4 * r + kq][8 * c + (fl & 7)];
-                const double b = fl < 8 ? x : x * x;
+                const double b = xs[4 * r + kq][bcol + 8 * c];      // lanes 0-7 of a row: the linear columns; 8-15: the squares
                 acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[r], b, acc[c], 0, 0, 0);
             }
         }
