@@ -367,9 +367,11 @@ void srx_decode_plan_destroy(srx_decode_plan *plan);
  * SRX_DECODE_FRONTIER: per frame only the states inside the beam (the reference's `layer` map restricted to what
  * src/hmm.cpp:165 lets through) push their transitions; back-pointers are kept per frontier member (8 bytes each), so the
  * memory follows the beam, not frames * n_states; the whole GPU works on one frame -- the full lexicon of
- * src/main.cpp:58 (about 10^6 states).  SRX_DECODE_AUTO (default): dense up to 32,768 states and 256 MB of back-pointers.
- * max_workspace_bytes (0: keep, default 2 GiB) bounds the frontier sweep's workspace; an utterance whose frontier outgrows
- * its share gets status 3.  No counterpart in the reference (a tuning knob). */
+ * src/main.cpp:58 (about 10^6 states).  SRX_DECODE_AUTO (default): dense up to 32,768 states while the longest utterance's
+ * back-pointers fit half the workspace limit.  max_workspace_bytes (0: keep, default 2 GiB) bounds both: the dense sweep
+ * takes the utterances in groups whose back-pointers fit half of it, the frontier sweep keeps its per-state arrays and its
+ * store inside it; an utterance whose frontier outgrows its share gets status 3.  No counterpart in the reference (a
+ * tuning knob). */
 enum { SRX_DECODE_AUTO = 0, SRX_DECODE_DENSE = 1, SRX_DECODE_FRONTIER = 2 };
 int srx_decode_plan_set_sweep(srx_decode_plan *plan, int sweep, size_t max_workspace_bytes);
 

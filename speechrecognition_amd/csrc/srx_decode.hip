@@ -377,42 +377,61 @@ extern "C" int srx_viterbi_graph_dev(srx_ctx *ctx, const srx_decode_plan *plan, 
     SRX_REQUIRE(ctx, final_mode == 0 || final_mode == 1, "srx_viterbi_graph_dev: final_mode %d", final_mode);
     if (n_utt == 0) return SRX_OK;
     const int n = plan->n_states;
-    std::vector<int64_t> bp_off((size_t)n_utt + 1, 0);
+    int64_t tmax = 0;
     for (int u = 0; u < n_utt; u++) {
         SRX_REQUIRE(ctx, frame_off[u + 1] >= frame_off[u] && frame_off[u + 1] - frame_off[u] < (1ll << 31), "srx_viterbi_graph_dev: bad frame offsets");
-        bp_off[(size_t)u + 1] = bp_off[u] + (frame_off[u + 1] - frame_off[u]) * n;
+        tmax = std::max<int64_t>(tmax, frame_off[u + 1] - frame_off[u]);
     }
-    // the dense sweep keeps one int32 back-pointer per (frame, state) and visits every state every frame: right for lexica of
-    // a few thousand states and many utterances at once; beyond that the frontier sweep (srx_decode_frontier.hip)
-    const bool dense_fits = n <= 32768 && (size_t)bp_off[n_utt] * 4 <= ((size_t)256 << 20);
+    // The dense sweep keeps one int32 back-pointer per (frame, state) and visits every state every frame with one workgroup per
+    // utterance: right for lexica of some thousands of states and many utterances at once (they go in groups whose back-pointers
+    // fit the plan's workspace limit).  Beyond that -- or when one utterance alone would not fit -- the frontier sweep
+    // (srx_decode_frontier.hip).
+    const size_t limit = plan->max_workspace;
+    const bool dense_fits = n <= 32768 && (size_t)tmax * n * 4 + 4 <= limit / 2;
     if (plan->sweep == SRX_DECODE_FRONTIER || (plan->sweep == SRX_DECODE_AUTO && !dense_fits))
         return srx_viterbi_frontier(ctx, plan, emis_dev, stride_t, stride_g, frame_off, n_utt, beam_width, final_mode, path_dev, final_logp_dev,
                                     final_state_dev, status_dev);
-    // workspace (slot 1, shared with the alignment kernel's back-pointers): frame and back-pointer offsets, delta, flags,
-    // running values, back-pointers
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t b_foff = up(((size_t)n_utt + 1) * 8), b_bpo = b_foff, b_d = up((size_t)n_utt * 2 * n * 4), b_a = up((size_t)n_utt * 2 * n),
-                 b_p = up((size_t)n_utt * (plan->n_pre > 0 ? plan->n_pre : 1) * 4), b_bp = up((size_t)bp_off[n_utt] * 4 + 4);
-    void *ws = nullptr;
-    int rc = srx_workspace(ctx, 1, b_foff + b_bpo + b_d + b_a + b_p + b_bp, &ws);
-    if (rc != SRX_OK) return rc;
-    char *w = reinterpret_cast<char *>(ws);
-    int64_t *foff_d = reinterpret_cast<int64_t *>(w);
-    int64_t *bpo_d = reinterpret_cast<int64_t *>(w + b_foff);
-    float *dws = reinterpret_cast<float *>(w + b_foff + b_bpo);
-    unsigned char *aws = reinterpret_cast<unsigned char *>(w + b_foff + b_bpo + b_d);
-    float *pws = reinterpret_cast<float *>(w + b_foff + b_bpo + b_d + b_a);
-    int32_t *bpws = reinterpret_cast<int32_t *>(w + b_foff + b_bpo + b_d + b_a + b_p);
-    SRX_HIP(ctx, hipMemcpyAsync(foff_d, frame_off, ((size_t)n_utt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    SRX_HIP(ctx, hipMemcpyAsync(bpo_d, bp_off.data(), ((size_t)n_utt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the two host arrays above are about to go out of scope
-    {
-        SrxProf prof_(ctx, "k_viterbi_graph");
-        hipLaunchKernelGGL(k_viterbi_graph, dim3(n_utt), dim3(DEC_THREADS), 0, ctx->stream, n, plan->tr_off, plan->tr_tgt, plan->tr_logp,
-                           plan->tied, plan->in_off, plan->in_src, plan->in_k, plan->in_pre, plan->n_fan, plan->fan_src, plan->fan_pre,
-                           plan->n_big, plan->big_tgt, plan->n_pre, emis_dev, stride_t, stride_g, foff_d, bpo_d, beam_width, final_mode, dws, aws,
-                           pws, bpws, path_dev, final_logp_dev, final_state_dev, status_dev);
+    const size_t npre = (size_t)(plan->n_pre > 0 ? plan->n_pre : 1);
+    int u0 = 0;
+    while (u0 < n_utt) {
+        // a group of consecutive utterances: back-pointers within half the limit (SRX_DECODE_DENSE forced on a single utterance
+        // larger than that still runs, alone)
+        int U = 0;
+        std::vector<int64_t> bp_off(1, 0);
+        while (u0 + U < n_utt) {
+            const int64_t add = (frame_off[u0 + U + 1] - frame_off[u0 + U]) * n;
+            if (U > 0 && (size_t)(bp_off.back() + add) * 4 > limit / 2) break;
+            bp_off.push_back(bp_off.back() + add);
+            U++;
+        }
+        // workspace (slot 1, shared with the alignment kernel's back-pointers): frame and back-pointer offsets, delta, flags,
+        // running values, back-pointers
+        const size_t b_foff = up(((size_t)U + 1) * 8), b_bpo = b_foff, b_d = up((size_t)U * 2 * n * 4), b_a = up((size_t)U * 2 * n),
+                     b_p = up((size_t)U * npre * 4), b_bp = up((size_t)bp_off[U] * 4 + 4);
+        void *ws = nullptr;
+        int rc = srx_workspace(ctx, 1, b_foff + b_bpo + b_d + b_a + b_p + b_bp, &ws);
+        if (rc != SRX_OK) return rc;
+        char *w = reinterpret_cast<char *>(ws);
+        int64_t *foff_d = reinterpret_cast<int64_t *>(w);
+        int64_t *bpo_d = reinterpret_cast<int64_t *>(w + b_foff);
+        float *dws = reinterpret_cast<float *>(w + b_foff + b_bpo);
+        unsigned char *aws = reinterpret_cast<unsigned char *>(w + b_foff + b_bpo + b_d);
+        float *pws = reinterpret_cast<float *>(w + b_foff + b_bpo + b_d + b_a);
+        int32_t *bpws = reinterpret_cast<int32_t *>(w + b_foff + b_bpo + b_d + b_a + b_p);
+        SRX_HIP(ctx, hipMemcpyAsync(foff_d, frame_off + u0, ((size_t)U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(bpo_d, bp_off.data(), ((size_t)U + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the two host arrays above are about to go out of scope
+        {
+            SrxProf prof_(ctx, "k_viterbi_graph");
+            hipLaunchKernelGGL(k_viterbi_graph, dim3(U), dim3(DEC_THREADS), 0, ctx->stream, n, plan->tr_off, plan->tr_tgt, plan->tr_logp,
+                               plan->tied, plan->in_off, plan->in_src, plan->in_k, plan->in_pre, plan->n_fan, plan->fan_src, plan->fan_pre,
+                               plan->n_big, plan->big_tgt, plan->n_pre, emis_dev, stride_t, stride_g, foff_d, bpo_d, beam_width, final_mode, dws, aws,
+                               pws, bpws, path_dev, final_logp_dev + u0, final_state_dev ? final_state_dev + u0 : nullptr, status_dev + u0);
+        }
+        SRX_LAUNCH_CHECK(ctx);
+        u0 += U;
+        if (u0 < n_utt) SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the next group reuses the workspace
     }
-    SRX_LAUNCH_CHECK(ctx);
     return SRX_OK;
 }

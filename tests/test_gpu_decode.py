@@ -246,3 +246,22 @@ def test_frontier_sweep_at_reference_lexicon_size_bit_exact(ctx, oracle, n_words
     path, final, _, st = hmm.viterbi(emis_d, G, 1, fo, 200.0, 1)
     assert list(st) == [0, 0]
     hmm.close()
+
+
+def test_dense_sweep_in_utterance_groups(ctx, oracle):
+    """The dense sweep's back-pointers (4 * frames * states bytes) are bounded by the plan's workspace limit: the utterances go
+    in groups that fit half of it.  Same results as in one launch."""
+    rng = np.random.default_rng(5)
+    words, uni = _lexicon(rng, 40)
+    a = host.build_lexicon_hmm(words, uni)
+    tied = a["ctx"][:, 1].copy()
+    emis, fo = _emissions_for(rng, a, words, 7, 9)
+    emis_d = ctx.array(emis)
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    per_utt = int(np.diff(fo).max()) * a["n_states"] * 4
+    hmm.set_sweep(host.DECODE_DENSE, 2 * 2 * per_utt + 1024)         # two of the longest utterances per group at most
+    _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 300.0, 1, expect_ok=9)
+    _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 1e10, 0)
+    hmm.set_sweep(host.DECODE_AUTO, 2 * per_utt // 2)                # not even one fits: AUTO goes to the frontier sweep
+    _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 300.0, 1, expect_ok=9)
+    hmm.close()
