@@ -130,3 +130,25 @@ def test_full_reference_lexicon_host_layer_vs_restatement():
         n_ok += e != "!1"
         n_giveup += e == "!1"
     assert n_ok > 1000 and n_giveup > 100
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_LEX, "cmu.txt")), reason="reference lexicon not on this machine")
+def test_full_reference_lexicon_hmm_topology():
+    """The lexicon HMM that src/main.cpp:58 builds from res/lexicon/cmu.txt (src/hmm.cpp:92-129): the C ABI's host-side
+    constructor against the oracle's, on the real lexicon -- spelling-sorted words, first pronunciation each.  (Decoding on an
+    HMM of this size is tested on the GPU with synthetic words of the same count, tests/test_gpu_decode.py.)"""
+    import numpy as np
+    from oracle import oracle as O
+    from speechrecognition_amd import host
+    O.build()
+    pr = P.load(*[os.path.join(REF_LEX, n) for n in ("cmu.txt", "prefixes.txt", "suffixes.txt")])
+    entries = {w: np.array(p[0], np.int32) for w, p in pr.main.items() if len(p[0]) > 0}
+    spell = sorted(entries)
+    words = [entries[w] for w in spell]
+    uni = np.full(len(words), -np.float32(np.log(1000.0)), np.float32)
+    a = host.build_lexicon_hmm(words, uni)
+    b = O.build_lexicon_hmm(words, uni)
+    assert a["n_states"] == b["n_states"] == 1 + sum(len(w) + 1 for w in words)
+    assert a["n_states"] > 900000 and len(words) > 120000
+    for k in ("tr_off", "tr_tgt", "tr_logp", "ctx", "word_of"):
+        assert a[k].tobytes() == b[k].tobytes(), k
