@@ -578,7 +578,11 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
     const int e0 = NV * kq;
     const int nvalid = D - e0 < NV ? (D - e0 < 0 ? 0 : D - e0) : NV;   // columns of this lane's slice that exist in a row
     auto load_row = [&](int o, float (&x)[NV]) __attribute__((always_inline)) {
+#ifdef SRX_FUSED_EXP_NOGATHER
+        const float *row = feats + (int64_t)(o >= 0 ? (o & 1023) : 0) * ld + e0;   // L2-hot rows
+#else
         const float *row = feats + (int64_t)(o >= 0 ? o : 0) * ld + e0;
+#endif
 #pragma unroll
         for (int q4 = 0; q4 < NV; q4 += 4) {
             if (q4 + 4 <= NV && nvalid >= q4 + 4) {
@@ -635,15 +639,23 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
             // two independent accumulation chains (linear and quadratic columns) so that consecutive MFMAs do not wait on each other
             f64x4 L = (f64x4){0.0, 0.0, 0.0, 0.0}, Q = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
+#ifdef SRX_FUSED_EXP_NOLOGP
+            for (int kk = 0; kk < NV; kk++) { L[kk & 3] += v1[kk] * wreg[kk]; Q[kk & 3] += v1[kk] * wreg[NV + kk]; }
+#else
             for (int kk = 0; kk < NV; kk++) {
                 L = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk], wreg[kk], L, 0, 0, 0);
                 Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v1[kk] * v1[kk], wreg[NV + kk], Q, 0, 0, 0);
             }
+#endif
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const bool valid = 16 * t + 4 * r + kq < nfr;
                 // zeta = weight * prob (src/hmm.cpp:282,307,328) relative to the component's peak density
+#ifdef SRX_FUSED_EXP_NOEXP   // diagnostic builds (tools/em_variant.py): wrong results, timing only
+                z[r] = valid ? wm * (L[r] + Q[r]) : 0.0;
+#else
                 z[r] = valid ? wm * srx_exp_f64(L[r] + Q[r]) : 0.0;
+#endif
             }
         } else {
 #pragma unroll
@@ -655,7 +667,11 @@ __global__ __launch_bounds__(64, SRX_FUSED_WPE) void k_em_fused(const float *__r
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const double b = xs[4 * r + kq][bcol + 8 * c];      // lanes 0-7 of a row: the linear columns; 8-15: the squares
+#ifdef SRX_FUSED_EXP_NOACC
+                acc[c][r] += z[r] * b;
+#else
                 acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(z[r], b, acc[c], 0, 0, 0);
+#endif
             }
         }
         __syncthreads();   // the tile is consumed before the next one is written
