@@ -22,7 +22,8 @@
 // delta and the activity flags (the reference's `layer` maps: a state is in the map or not) live in global memory, so
 // the state count is bounded by memory, not by LDS; back-pointers are one int32 per (frame, state).  Every state is
 // visited every frame (activity is a flag, not a list): the sweep is dense, which a lexicon of a few thousand states
-// does not notice; a frontier list would be the next step for the full 125 k-word lexicon.
+// does not notice.  The full 125 k-word lexicon (10^6 states) goes through the frontier sweep of srx_decode_frontier.hip
+// (srx_decode_plan_set_sweep; chosen automatically), which gives the same results bit for bit.
 // NaN emission scores (tied states whose parameters are NaN because training never visited them) are outside the
 // contract: the reference's result then depends on its map order; here a NaN candidate that arrives first is kept, as
 // in the reference, for ordinary targets, while the workgroup reduction of a fan-in target may pick differently.
