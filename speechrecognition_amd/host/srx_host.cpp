@@ -1064,6 +1064,21 @@ float unigram_model::get(string w) const {
     return it != probs.end() ? it->second : -logtotal;   // an unseen word counts as seen once
 }
 
+bigram_model::bigram_model(unigram_model *u, long count) : total_count(count), logtotal((float)std::log((double)count)), uni(u) {}
+bigram_model::bigram_model(std::istream &in, unigram_model *u, long count)
+    : total_count(count), logtotal((float)std::log((double)count)), uni(u) {
+    string w1, w2;
+    long c;
+    while (in >> w1 >> w2 >> c) put(w1, w2, c);
+}
+void bigram_model::put(string w1, string w2, long count) {   // src/langmodel.cpp:31-34
+    probs[w1 + "^" + w2] = (float)(std::log((double)count) - (double)logtotal);
+}
+float bigram_model::get(string w1, string w2) const {        // src/langmodel.cpp:37-44
+    std::map<string, float>::const_iterator it = probs.find(w1 + "^" + w2);
+    return it != probs.end() ? it->second - uni->get(w1) : uni->get(w2);
+}
+
 // ============================================================================================ hmm
 hmm_state::hmm_state(phspec p) : ph(p), ctx(phone::context(p.first)), word(nullptr) {}
 float hmm_state::get_logprob(int i) const { return tr[i].second; }

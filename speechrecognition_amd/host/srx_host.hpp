@@ -286,6 +286,19 @@ public:
     void put(std::string w, long count);                      // src/langmodel.cpp:16-19
     float get(std::string w) const;                           // src/langmodel.cpp:22-28
 };
+// Bigram log-probabilities with unigram back-off (src/langmodel.hpp:48-65, src/langmodel.cpp:31-44).  The reference builds none
+// (its main() never constructs one); here for callers that switch over with code that does.
+class bigram_model {
+public:
+    std::map<std::string, float> probs;                       // key "w1^w2"
+    long total_count;
+    float logtotal;
+    unigram_model *uni;                                       // the model to fall back on for bigrams never seen
+    bigram_model(unigram_model *u, long total_count);
+    bigram_model(std::istream &in, unigram_model *u, long total_count);   // one "w1 w2 count" triple per line
+    void put(std::string w1, std::string w2, long count);
+    float get(std::string w1, std::string w2) const;          // log P(w2 | w1)
+};
 
 // ------------------------------------------------------------------------------------------ gmm.hpp
 typedef long double prob_t;

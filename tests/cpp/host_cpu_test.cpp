@@ -210,6 +210,15 @@ int main(int argc, char **argv) {
         unigram_model uni(in, 1000);
         unigram_model none(1000);
         none.put("word", 10);
+        // bigram with unigram back-off (src/langmodel.cpp:31-44): log P(w2 | w1) = log c(w1 w2)/N - log c(w1)/N, else the unigram of w2
+        istringstream bin("the cat 10\nthe dog 5\nbroken line\n");
+        bigram_model bi(bin, &uni, 1000);
+        const float want = (float)(log(10.0) - (double)(float)log(1000.0)) - uni.get("the");
+        CHECK(fabsf(bi.get("the", "cat") - want) <= 1e-6f);
+        CHECK(bi.get("cat", "the") == uni.get("the"));                 // never seen: the unigram of w2
+        CHECK(bi.get("cat", "zebra") == -(float)log(1000.0));          // ... which for an unseen word is -logtotal
+        bigram_model empty(&none, 1000);
+        CHECK(empty.get("a", "word") == none.get("word"));
     }
     puts("ok unigram");
 
