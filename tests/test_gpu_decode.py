@@ -265,3 +265,31 @@ def test_dense_sweep_in_utterance_groups(ctx, oracle):
     hmm.set_sweep(host.DECODE_AUTO, 2 * per_utt // 2)                # not even one fits: AUTO goes to the frontier sweep
     _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 300.0, 1, expect_ok=9)
     hmm.close()
+
+
+def test_frontier_sweep_more_utterances_than_fit_in_flight(ctx, oracle):
+    """The frontier sweep keeps at most 32 utterances in flight (fewer under a small workspace limit) and takes a batch in
+    groups: 70 utterances, results equal to the dense sweep's for all of them and to the oracle's for a sample."""
+    rng = np.random.default_rng(17)
+    words, uni = _lexicon(rng, 25)
+    a = host.build_lexicon_hmm(words, uni)
+    tied = a["ctx"][:, 1].copy()
+    emis, fo = _emissions_for(rng, a, words, 6, 70)
+    emis_d = ctx.array(emis)
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    hmm.set_sweep(host.DECODE_DENSE)
+    ref = hmm.viterbi(emis_d, G, 1, fo, 250.0, 1)
+    for limit in (0, 3 << 20):                                    # default limit (groups of 32), and one that carries only a few
+        hmm.set_sweep(host.DECODE_FRONTIER, limit)
+        got = hmm.viterbi(emis_d, G, 1, fo, 250.0, 1)
+        assert np.array_equal(got[3], ref[3]) and (got[3] == 0).sum() >= 60
+        ok = ref[3] == 0
+        assert got[1][ok].tobytes() == ref[1][ok].tobytes() and np.array_equal(got[2][ok], ref[2][ok])
+        for u in np.flatnonzero(ok):
+            assert np.array_equal(got[0][fo[u]:fo[u + 1]], ref[0][fo[u]:fo[u + 1]]), u
+    for u in (0, 33, 69):
+        r = oracle.viterbi_graph(emis[fo[u]:fo[u + 1]], tied, a["tr_off"], a["tr_tgt"], a["tr_logp"], 250.0, 0, 1)
+        assert ref[3][u] == r["status"]
+        if r["status"] == 0:
+            assert ref[1][u].tobytes() == r["final"].tobytes() and np.array_equal(ref[0][fo[u]:fo[u + 1]], r["path"])
+    hmm.close()
