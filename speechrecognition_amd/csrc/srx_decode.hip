@@ -104,12 +104,53 @@ static hipError_t to_device(T **dst, const std::vector<T> &h) {
     return h.empty() ? hipSuccess : hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
+// Suffix maxima / magnitude sums of the wide sources' transition scores at tile boundaries (they move with the scores).
+static int wide_suffix_tables(srx_decode_plan *p, const float *tr_logp) {
+    srx_ctx *ctx = p->ctx;
+    std::vector<int32_t> off(1, 0);
+    std::vector<float> lpmax;
+    std::vector<double> lpabs;
+    for (size_t w = 0; w < p->h_wide_src.size(); w++) {
+        const int s = p->h_wide_src[w];
+        const int t0 = p->h_tr_off[s], K = p->h_tr_off[s + 1] - t0;
+        const int nt = (K + FR_TILE - 1) / FR_TILE;
+        const size_t base = lpmax.size();
+        lpmax.resize(base + nt);
+        lpabs.resize(base + nt);
+        float mx = -__builtin_huge_valf();
+        double sum = 0.0;
+        for (int k = K - 1; k >= 0; k--) {
+            const float v = tr_logp[t0 + k];
+            if (!(v <= mx)) mx = v;               // a NaN score ends up in mx: the kernel's test then never passes
+            sum += fabs((double)v);
+            if (k % FR_TILE == 0) {
+                lpmax[base + k / FR_TILE] = mx;
+                lpabs[base + k / FR_TILE] = sum;
+            }
+        }
+        off.push_back((int32_t)lpmax.size());
+    }
+    if (!p->wtile_off) {
+        hipError_t e;
+        if ((e = to_device(&p->wtile_off, off)) != hipSuccess || (e = to_device(&p->wtile_lpmax, lpmax)) != hipSuccess ||
+            (e = to_device(&p->wtile_lpabs, lpabs)) != hipSuccess)
+            return srx_fail(ctx, SRX_ERR_NOMEM, "srx_decode_plan: %s", hipGetErrorString(e));
+        return SRX_OK;
+    }
+    if (!lpmax.empty()) {
+        SRX_HIP(ctx, hipMemcpy(p->wtile_lpmax, lpmax.data(), lpmax.size() * sizeof(float), hipMemcpyHostToDevice));
+        SRX_HIP(ctx, hipMemcpy(p->wtile_lpabs, lpabs.data(), lpabs.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return SRX_OK;
+}
+
 extern "C" void srx_decode_plan_destroy(srx_decode_plan *p) {
     if (!p) return;
     (void)hipFree(p->tr_off); (void)hipFree(p->tr_tgt); (void)hipFree(p->tied); (void)hipFree(p->tr_logp);
     (void)hipFree(p->in_off); (void)hipFree(p->in_src); (void)hipFree(p->in_k); (void)hipFree(p->in_pre);
     (void)hipFree(p->fan_src); (void)hipFree(p->fan_pre); (void)hipFree(p->big_tgt);
     (void)hipFree(p->wide_of); (void)hipFree(p->wide_src); (void)hipFree(p->wide_pre); (void)hipFree(p->wpre_fan); (void)hipFree(p->wpre_tied);
+    (void)hipFree(p->wtile_off); (void)hipFree(p->wtile_lpmax); (void)hipFree(p->wtile_lpabs);
     delete p;
 }
 
@@ -184,6 +225,16 @@ extern "C" int srx_decode_plan_create(srx_ctx *ctx, int n_states, const int32_t 
         srx_decode_plan_destroy(p);
         return srx_fail(ctx, e == hipErrorOutOfMemory ? SRX_ERR_NOMEM : SRX_ERR_DEVICE, "srx_decode_plan_create: %s", hipGetErrorString(e));
     }
+    p->h_tr_off.assign(tr_off, tr_off + n_states + 1);
+    p->h_wide_src = wide_src;
+    for (int s_ = 0; s_ < n_states; s_++) p->n_cols = std::max(p->n_cols, tied[s_] + 1);
+    {
+        const int rc = wide_suffix_tables(p, tr_logp);
+        if (rc != SRX_OK) {
+            srx_decode_plan_destroy(p);
+            return rc;
+        }
+    }
     *out = p;
     return SRX_OK;
 }
@@ -195,7 +246,7 @@ extern "C" int srx_decode_plan_set_transitions(srx_decode_plan *p, const float *
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SRX_HIP(ctx, hipMemcpy(p->tr_logp, tr_logp, (size_t)p->n_tr * sizeof(float), hipMemcpyHostToDevice));
-    return SRX_OK;
+    return wide_suffix_tables(p, tr_logp);
 }
 
 extern "C" int srx_decode_plan_set_sweep(srx_decode_plan *p, int sweep, size_t max_workspace_bytes) {

@@ -31,7 +31,6 @@
 namespace {
 
 constexpr int FR_THREADS = 256;
-constexpr int FR_TILE = 1024;      // transitions of a wide source staged in LDS at a time
 
 struct FrCtl {
     int n_touched;
@@ -46,7 +45,10 @@ struct FrArgs {
     const int32_t *tr_off, *tr_tgt, *tied;
     const float *tr_logp;
     int n_wide, n_wpre;
-    const int32_t *wide_of, *wide_src, *wide_pre, *wpre_fan, *wpre_tied;
+    const int32_t *wide_of, *wide_src, *wide_pre, *wpre_fan, *wpre_tied, *wtile_off;
+    const float *wtile_lpmax;
+    const double *wtile_lpabs;
+    int n_cols;
     const float *emis;
     int64_t st_t, st_g;
     const int64_t *foff;            // [U + 1] frame offsets of the utterances in flight
@@ -58,6 +60,7 @@ struct FrArgs {
     float *fval;                    // [U][2][n] value of F_t's p-th member
     float *pre;                     // [U][n_wpre] running values of the wide sources
     int32_t *wact;                  // [U][2][n_wide] 1 + position in F_t of a wide source that is a member, else 0
+    int32_t *wdone;                 // [U][n_wide] transitions of a wide member whose running values exist this frame
     FrCtl *ctl;                     // [U]
     int64_t *fs_off;                // [U][tmax + 2] start of F_t in the store
     int32_t *st_state, *st_back;    // [U][cap]
@@ -189,6 +192,30 @@ __global__ __launch_bounds__(64) void k_fr_chain(FrArgs a, int t) {
     fetch_ix(0);
     fetch(0);
     fetch_ix(FR_TILE);
+    // Stopping early.  Once the running value is below (a lower bound of) next frame's threshold AND can never come back up,
+    // the rest of the list only produces values that k_fr_wpush would drop (not on an utterance's last frame, where it drops
+    // nothing).  "Never come back up" is decided without touching the rest: every remaining step adds a transition score
+    // <= lpmax (suffix maximum, from the plan) and an emission score <= gpos (this frame's largest, 0 if all are negative);
+    // with d = -(lpmax + gpos) > 0 a step computes fl(fl(x + lp) + g) <= x - d + ulp(M), M bounding every magnitude on the way
+    // (|x| + the remaining |lp| + the remaining steps * the frame's largest |emission|), so d >= ulp(M) makes the values
+    // non-increasing from here on.  ulp(M) <= 2^-22 M; 2.5e-7 is used.  Any NaN emission switches the test off.
+    const bool last_frame = t == T - 1;
+    float gpos = 0.0f, gabs = 0.0f;
+    int nan_seen = 0;
+    for (int c = lane; c < a.n_cols; c += 64) {
+        const float v = e_t[(int64_t)c * a.st_g];
+        nan_seen |= !(v == v);
+        gpos = fmaxf(gpos, v);
+        gabs = fmaxf(gabs, fabsf(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        gpos = fmaxf(gpos, __shfl_xor(gpos, o, 64));
+        gabs = fmaxf(gabs, __shfl_xor(gabs, o, 64));
+        nan_seen |= __shfl_xor(nan_seen, o, 64);
+    }
+    const float best_before = o2f(a.ctl[u].best_bits);      // the ordinary members have all offered (k_fr_push ran before)
+    const int tile0 = a.wtile_off[fi];
+    int ndone = K;
     for (int k0 = 0; k0 < K; k0 += FR_TILE) {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
@@ -232,9 +259,24 @@ __global__ __launch_bounds__(64) void k_fr_chain(FrArgs a, int t) {
             best = fmaxf(best, v);
         }
         __syncthreads();
+        if (!last_frame && !nan_seen && k0 + FR_TILE < K) {
+            for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+            const float x_end = __shfl(x, 0, 64);
+            const float thr_lb = fmaxf(best_before, best) - a.beam;       // <= next frame's threshold: the frame's best only grows
+            const int ti = tile0 + k0 / FR_TILE + 1;
+            const double d = -((double)a.wtile_lpmax[ti] + (double)gpos);
+            const double M = fabs((double)x_end) + a.wtile_lpabs[ti] + (double)(K - (k0 + FR_TILE)) * (double)gabs;
+            if (x_end < thr_lb && d > 0.0 && d >= 2.5e-7 * M) {
+                ndone = k0 + FR_TILE;
+                break;
+            }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
-    if (lane == 0 && best > -1e10f) atomicMax(&a.ctl[u].best_bits, f2o(best));
+    if (lane == 0) {
+        a.wdone[(size_t)u * a.n_wide + fi] = ndone;
+        if (best > -1e10f) atomicMax(&a.ctl[u].best_bits, f2o(best));
+    }
 }
 
 // the candidates of the wide members, in parallel; the frame's best value is final by now
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_fr_wpush(FrArgs a, int t) {
     const float *pre = a.pre + (size_t)u * a.n_wpre;
     for (int e = blockIdx.x * FR_THREADS + threadIdx.x; e < a.n_wpre; e += gridDim.x * FR_THREADS) {
         const int fi = a.wpre_fan[e];
-        if (!wact[fi]) continue;
+        if (!wact[fi] || e - a.wide_pre[fi] >= a.wdone[(size_t)u * a.n_wide + fi]) continue;   // not a member / the chain stopped before
         const float x = pre[e];
         if (!last && x < thr_next) continue;
         const int s = a.wide_src[fi];
@@ -395,7 +437,7 @@ int srx_viterbi_frontier(srx_ctx *ctx, const srx_decode_plan *plan, const float 
     while (u0 < n_utt) {
         // utterances in flight: as many as the workspace limit carries with a store of sixteen full layers each (or all the
         // layers there can be, if that is less)
-        const size_t fixed = up(n * 8) + up(n * 4) + 2 * up(2 * n * 4) + up(nwp * 4) + up(2 * nw * 4) + 256;
+        const size_t fixed = up(n * 8) + up(n * 4) + 2 * up(2 * n * 4) + up(nwp * 4) + up(2 * nw * 4) + up(nw * 4) + 256;
         int tmax_rem = 0;
         for (int u = u0; u < n_utt; u++) tmax_rem = std::max<int>(tmax_rem, (int)(frame_off[u + 1] - frame_off[u]));
         const size_t store_goal = 8 * std::min(((size_t)tmax_rem + 1) * n + 1, 16 * n + 1);
@@ -411,10 +453,11 @@ int srx_viterbi_frontier(srx_ctx *ctx, const srx_decode_plan *plan, const float 
         const size_t cap = std::min(want, room / (8 * (size_t)U));
         SRX_REQUIRE(ctx, cap >= std::min(want, 2 * n + 1), "srx_viterbi_graph_dev: the workspace limit of %zu bytes is too small for %zu states",
                     plan->max_workspace, n);
+        const size_t b_wdone = up(nw * 4) * U;
         const size_t b_cand = up(n * 8) * U, b_touch = up(n * 4) * U, b_pos = up(2 * n * 4) * U, b_fval = b_pos, b_pre = up(nwp * 4) * U,
                      b_wact = up(2 * nw * 4) * U, b_ctl = up(sizeof(FrCtl) * U), b_fso = per_off * U, b_st = up(cap * 4 * U);
         void *ws = nullptr;
-        int rc = srx_workspace(ctx, 1, head + b_cand + b_touch + b_pos + b_fval + b_pre + b_wact + b_ctl + b_fso + 2 * b_st, &ws);
+        int rc = srx_workspace(ctx, 1, head + b_cand + b_touch + b_pos + b_fval + b_pre + b_wact + b_wdone + b_ctl + b_fso + 2 * b_st, &ws);
         if (rc != SRX_OK) return rc;
         char *w = reinterpret_cast<char *>(ws);
         FrArgs a;
@@ -422,6 +465,7 @@ int srx_viterbi_frontier(srx_ctx *ctx, const srx_decode_plan *plan, const float 
         a.tr_off = plan->tr_off; a.tr_tgt = plan->tr_tgt; a.tied = plan->tied; a.tr_logp = plan->tr_logp;
         a.n_wide = plan->n_wide; a.n_wpre = plan->n_wpre;
         a.wide_of = plan->wide_of; a.wide_src = plan->wide_src; a.wide_pre = plan->wide_pre; a.wpre_fan = plan->wpre_fan; a.wpre_tied = plan->wpre_tied;
+        a.wtile_off = plan->wtile_off; a.wtile_lpmax = plan->wtile_lpmax; a.wtile_lpabs = plan->wtile_lpabs; a.n_cols = plan->n_cols;
         a.emis = emis_dev; a.st_t = stride_t; a.st_g = stride_g;
         a.beam = beam_width; a.final_mode = final_mode;
         a.foff = reinterpret_cast<const int64_t *>(w); w += head;
@@ -432,6 +476,7 @@ int srx_viterbi_frontier(srx_ctx *ctx, const srx_decode_plan *plan, const float 
         a.fval = reinterpret_cast<float *>(w); w += b_fval;
         a.pre = reinterpret_cast<float *>(w); w += b_pre;
         a.wact = reinterpret_cast<int32_t *>(w); w += b_wact;
+        a.wdone = reinterpret_cast<int32_t *>(w); w += b_wdone;
         a.ctl = reinterpret_cast<FrCtl *>(w); w += b_ctl;
         a.fs_off = reinterpret_cast<int64_t *>(w); w += b_fso;
         a.st_state = reinterpret_cast<int32_t *>(w); w += b_st;

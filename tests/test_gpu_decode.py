@@ -293,3 +293,38 @@ def test_frontier_sweep_more_utterances_than_fit_in_flight(ctx, oracle):
         if r["status"] == 0:
             assert ref[1][u].tobytes() == r["final"].tobytes() and np.array_equal(ref[0][fo[u]:fo[u + 1]], r["path"])
     hmm.close()
+
+
+@pytest.mark.parametrize("shift", [0.0, 25.0, 130.0])
+def test_frontier_chain_early_stop_is_exact(ctx, oracle, shift):
+    """The start state's serial chain stops once its running value is below next frame's threshold and provably cannot come back
+    up (srx_decode_frontier.hip, k_fr_chain).  Three regimes on a 20,000-word lexicon (start transitions -94 .. -51): emission
+    scores all negative (every step goes down: the chain stops after its first tile), some positive but smaller than the
+    smallest language-model penalty (steps still go down, by less), and positive beyond it (the running value climbs along the
+    lexicon: the test never passes and the whole chain runs).  Bit-exact against the oracle in all three, both end conditions."""
+    n_words = 20000
+    rng = np.random.default_rng(31)
+    lens = np.clip(rng.poisson(5.4, n_words) + 1, 1, 20)
+    words = [rng.integers(1, 40, int(k)).astype(np.int32) for k in lens]
+    counts = rng.integers(1, 5000, n_words)
+    uni = (np.log(counts) - np.float32(np.log(counts.sum() * 3.0))).astype(np.float32)
+    a = host.build_lexicon_hmm(words, uni)
+    assert a["tr_logp"][:n_words].max() < -45 and a["tr_logp"][:n_words].min() > -100
+    tied = a["ctx"][:, 1].copy()
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    emis, fo = [], [0]
+    for seq in ([0, 2, 1], [3, 0], [5]):
+        rows = []
+        for w in seq:
+            for ph in list(words[w]) + [0]:
+                e = rng.standard_normal((int(rng.integers(2, 6)), G)).astype(np.float32) * 2 - 12 + np.float32(shift)
+                e[:, ph] += 9.0
+                rows.append(e)
+        emis.append(np.concatenate(rows))
+        fo.append(fo[-1] + len(emis[-1]))
+    emis, fo = np.concatenate(emis), np.array(fo, np.int64)
+    emis_d = ctx.array(emis)
+    for beam in (200.0, 40.0):
+        _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, beam, 1, expect_ok=3 if beam == 200.0 else None)
+        _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, beam, 0)
+    hmm.close()
