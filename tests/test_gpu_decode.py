@@ -328,3 +328,44 @@ def test_frontier_chain_early_stop_is_exact(ctx, oracle, shift):
         _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, beam, 1, expect_ok=3 if beam == 200.0 else None)
         _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, beam, 0)
     hmm.close()
+
+
+def test_frontier_early_stop_follows_set_transitions(ctx, oracle):
+    """srx_decode_plan_set_transitions refreshes what the chain's early stop relies on (the suffix maxima of the start state's
+    transition scores).  Here the new start transitions are half as negative as the old ones and the emission scores sit between
+    the two: with stale maxima the chain would stop where it must not.  Bit-exact against the oracle before and after."""
+    n_words = 3000
+    rng = np.random.default_rng(8)
+    lens = np.clip(rng.poisson(4.0, n_words) + 1, 1, 12)
+    words = [rng.integers(1, 40, int(k)).astype(np.int32) for k in lens]
+    counts = rng.integers(1, 5000, n_words)
+    uni = (np.log(counts) - np.float32(np.log(counts.sum() * 3.0))).astype(np.float32)
+    a = host.build_lexicon_hmm(words, uni)
+    tied = a["ctx"][:, 1].copy()
+    lo, hi = float(a["tr_logp"][:n_words].min()), float(a["tr_logp"][:n_words].max())
+    assert hi < -40
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], tied)
+    hmm.set_sweep(host.DECODE_FRONTIER)
+    rows = []
+    for w in (1, 0, 4):
+        for ph in list(words[w]) + [0]:
+            e = rng.standard_normal((int(rng.integers(2, 6)), G)).astype(np.float32) * 2 + np.float32(-hi * 0.75)   # positive, below |hi|
+            e[:, ph] += 4.0
+            rows.append(e)
+    emis = np.concatenate(rows)
+    fo = np.array([0, len(emis)], np.int64)
+    emis_d = ctx.array(emis)
+    assert emis.max() < -hi and emis.max() > -hi * 0.5 + 5
+    _check_against_oracle(oracle, hmm, a, tied, emis, emis_d, fo, 150.0, 1)
+    # new scores: the first tile of words still drags the running value down (below the threshold: the stale tables, whose
+    # suffix maximum is `hi`, would let the chain stop there), the rest are half as negative as before -- under these emissions
+    # the value climbs back and the best words are late in the lexicon
+    new_tr = a["tr_logp"].copy()
+    new_tr[:1024] = np.float32(hi * 0.9)
+    new_tr[1024:n_words] *= np.float32(0.5)
+    hmm.set_transitions(new_tr)
+    b = dict(a, tr_logp=new_tr)
+    path = _check_against_oracle(oracle, hmm, b, tied, emis, emis_d, fo, 150.0, 1)
+    assert a["word_of"][path].max() >= 1024               # the path does use words behind the first tile
+    _check_against_oracle(oracle, hmm, b, tied, emis, emis_d, fo, 150.0, 0)
+    hmm.close()
