@@ -104,9 +104,10 @@ int srx_mfcc_plan_create(srx_ctx *ctx, const srx_mfcc_cfg *cfg, const srx_filter
 void srx_mfcc_plan_destroy(srx_mfcc_plan *plan);
 int srx_mfcc_plan_bin_max(const srx_mfcc_plan *plan);
 /* Which matrix-core formulation srx_mfcc_batch* runs (same reference code replaced, same 1e-4 bar):
- * SRX_MFCC_F16X3: operands split into two f16 parts, three products on the f16 matrix cores (half windows of 160
- * or 200 samples, i.e. the reference's 320 and BASELINE's 400-sample windows); SRX_MFCC_F32: f32 matrix cores, any
- * window; SRX_MFCC_AUTO (default): F16X3 where it applies.  No counterpart in the reference (a tuning knob). */
+ * SRX_MFCC_F16X3: operands split into two f16 parts, three products on the f16 matrix cores (half windows of 113..128,
+ * 145..160, 193..208 or 241..256 samples: the reference's 320- and BASELINE's 400-sample windows, and 256 / 512);
+ * SRX_MFCC_F32: f32 matrix cores, any window; SRX_MFCC_AUTO (default): F16X3 where it applies.  No counterpart in the
+ * reference (a tuning knob). */
 enum { SRX_MFCC_AUTO = 0, SRX_MFCC_F32 = 1, SRX_MFCC_F16X3 = 2,
        SRX_MFCC_FFT = 3 /* the half-window transform as ONE packed real FFT of N/2 points in LDS (N/2 = 8*5*5, 8*5*4,
                            8*4*4, 8*8*4: windows of 400, 320, 256, 512 samples), f32 vector arithmetic, no matrix cores.

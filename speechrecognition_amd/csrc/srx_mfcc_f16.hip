@@ -50,7 +50,7 @@ static inline int acc_row(int r, int hh) { return (r % 4) + 8 * (r / 4) + 4 * hh
 
 int srx_mfcc16_supported(int half, int n_filters, int n_ceps, int bin_max) {
     const int ks = (half + 15) / 16;
-    return (ks == 10 || ks == 13) && n_filters <= 32 * NRT && n_ceps <= 16 && bin_max <= 256;
+    return (ks == 8 || ks == 10 || ks == 13 || ks == 16) && n_filters <= 32 * NRT && n_ceps <= 16 && bin_max <= 256;
 }
 
 static void split16(float v, _Float16 *hi, _Float16 *lo) {
@@ -433,6 +433,8 @@ int srx_mfcc16_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samp
     if (!attr_set[ctx->device]) {
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_mfcc_f16<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_mfcc_f16<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_mfcc_f16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void *)k_mfcc_f16<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[ctx->device] = true;
     }
     {
@@ -441,6 +443,10 @@ int srx_mfcc16_launch(srx_ctx *ctx, const srx_mfcc_plan *plan, const float *samp
             hipLaunchKernelGGL(k_mfcc_f16<10>, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, ctx->stream, a);
         else if (KS == 13)
             hipLaunchKernelGGL(k_mfcc_f16<13>, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, ctx->stream, a);
+        else if (KS == 8)
+            hipLaunchKernelGGL(k_mfcc_f16<8>, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, ctx->stream, a);
+        else if (KS == 16)
+            hipLaunchKernelGGL(k_mfcc_f16<16>, dim3((unsigned)nblk), dim3(64 * NW), lds_bytes, ctx->stream, a);
         else
             return srx_fail(ctx, SRX_ERR_UNSUPPORTED, "srx_mfcc_batch_dev: split-f16 path has no kernel for %d k-steps", KS);
     }

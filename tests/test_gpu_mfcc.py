@@ -137,6 +137,24 @@ def test_mirrored_bins_near_nyquist(ctx, oracle):
     plan.close()
 
 
+@pytest.mark.parametrize("wl,hop,nf,sps", [(256, 128, 24, 12000), (512, 160, 40, 16000), (256, 100, 20, 8000), (250, 80, 20, 8000)])
+def test_split_f16_path_other_windows(ctx, oracle, wl, hop, nf, sps):
+    """The split-f16 matrix-core path beyond the reference's 320 and BASELINE's 400 samples: half windows of up to 128 and of
+    241..256 samples (8 and 16 k-steps of 16) -- 256- and 512-sample windows -- including, at 12 kHz, the mirrored bins of
+    src/clip.cpp:186-192.  SRX_MFCC_AUTO picks it there too."""
+    fb, bm = host.mel_filterbank(0.45 * sps if sps != 12000 else 7200, nf, wl, sps)
+    lens = [3000, wl + 1, 2 * wl + 7, 9000]
+    off = np.zeros(len(lens) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    x = np.concatenate([synth.utterance_audio(60 + i, n) for i, n in enumerate(lens)])
+    ref = _oracle_batch(oracle, x, off, wl, hop, fb)
+    for path in (host.MFCC_F16X3, host.MFCC_AUTO):
+        plan = host.MfccPlan(ctx, host.mfcc_config(wl, hop), fb, path)
+        ceps, _ = plan.write_features(x, off)
+        assert ceps.shape == ref.shape and _frame_rel_err(ceps, ref) <= 1e-4
+        plan.close()
+
+
 @pytest.mark.parametrize("wl,hop,nf,sps", [(256, 128, 24, 12000), (512, 160, 40, 16000), (256, 100, 20, 8000)])
 def test_fft_path_other_windows_and_mirrored_bins(ctx, oracle, wl, hop, nf, sps):
     """The LDS FFT path on its other radix plans (half window 128 = 8*4*4, 256 = 8*8*4) and, at 12 kHz, with the top filter
