@@ -318,6 +318,46 @@ def training_leg(ctx, torch, dist, backend, rank, world, n_total, iters, warm):
     return out
 
 
+def decode_leg(ctx, n_words, T):
+    """SURVEY 8 f3: hmm::viterbi with a beam on the lexicon HMM of src/hmm.cpp:92-129 at the size src/main.cpp:58 builds it
+    (133,860 words: the line count of res/lexicon/cmu.txt; synthetic words with its length distribution), one utterance of T
+    frames with synthetic emission scores that spell words from the head of the lexicon.  Rank 0 only: decoding one utterance
+    does not shard."""
+    from speechrecognition_amd import host
+    rng = np.random.default_rng(1)
+    lens = np.clip(rng.poisson(5.4, n_words) + 1, 1, 20)
+    words = [rng.integers(1, 40, int(k)).astype(np.int32) for k in lens]
+    counts = rng.integers(1, 5000, n_words)
+    uni = (np.log(counts) - np.float32(np.log(counts.sum() * 3.0))).astype(np.float32)
+    a = host.build_lexicon_hmm(words, uni)
+    hmm = host.GraphHmm(ctx, a["tr_off"], a["tr_tgt"], a["tr_logp"], a["ctx"][:, 1].copy())
+    rows = []
+    while sum(len(r) for r in rows) < T:
+        w = int(rng.integers(0, 8))
+        for ph in list(words[w]) + [0]:
+            e = rng.standard_normal((int(rng.integers(3, 9)), 40)).astype(np.float32) * 2 - 12
+            e[:, ph] += 9.0
+            rows.append(e)
+    emis_d = ctx.array(np.concatenate(rows)[:T])
+    fo = np.array([0, T], np.int64)
+    out = {"workload": f"free decoding of one {T}-frame utterance over a {n_words}-word lexicon HMM (frontier sweep of srx_viterbi_graph_dev), "
+                       "recognition end condition (best active state)",
+           "n_states": int(a["n_states"]), "n_transitions": int(a["tr_off"][-1]), "runs": []}
+    for beam in (200.0, 1e10):
+        hmm.set_sweep(host.DECODE_FRONTIER, 8 << 30)
+        hmm.viterbi(emis_d, 40, 1, fo, beam, 1)
+        ctx.profile_enable(True)
+        path, final, fstate, status = hmm.viterbi(emis_d, 40, 1, fo, beam, 1)
+        ms, cnt = ctx.profile_query("k_viterbi_frontier")
+        ctx.profile_enable(False)
+        assert status[0] == 0, "decode failed"
+        out["runs"].append({"beam": beam, "device_ms": ms / max(cnt, 1), "x_real_time": T * 0.010 / (ms / max(cnt, 1) * 1e-3),
+                            "final_logp": float(final[0])})
+    assert out["runs"][0]["final_logp"] == out["runs"][1]["final_logp"]      # here the beam prunes nothing the best path needs
+    hmm.close()
+    return out
+
+
 def alignment_leg(ctx, torch, dist, backend, rank, world, n_total, reps):
     """BASELINE config 3/4: forced alignment of n_total utterances split across the ranks (strong scaling): alignment-mode
     scoring + Viterbi, no collective (utterances are independent)."""
@@ -366,6 +406,7 @@ def main():
     ap.add_argument("--train-utts", type=int, default=100000, help="config-5 training leg: utterances in the whole corpus (0: skip)")
     ap.add_argument("--train-iters", type=int, default=5)
     ap.add_argument("--align-utts", type=int, default=10000, help="config-3/4 alignment leg: utterances in the whole corpus (0: skip)")
+    ap.add_argument("--decode-words", type=int, default=133860, help="decode leg: words in the lexicon HMM (0: skip)")
     ap.add_argument("--score-path", choices=["f16x3", "f32"], default="f16x3",
                     help="GMM scoring kernel: split-f16 MFMA (default) or f32-input MFMA")
     args = ap.parse_args()
@@ -516,6 +557,9 @@ def main():
     if args.train_utts > 0:
         extra["train_config5"] = training_leg(ctx, torch, dist, backend, rank, world, args.train_utts, args.train_iters, 2)
 
+    if args.decode_words > 0 and rank == 0:
+        progress("decode leg (%d words)" % args.decode_words)
+        extra["decode_lexicon"] = decode_leg(ctx, args.decode_words, 500)
     progress("legs done")
     if rank == 0:
         ms_step = dt_max / args.steps * 1e3
