@@ -343,7 +343,7 @@ def decode_leg(ctx, n_words, T):
     out = {"workload": f"free decoding of one {T}-frame utterance over a {n_words}-word lexicon HMM (frontier sweep of srx_viterbi_graph_dev), "
                        "recognition end condition (best active state)",
            "n_states": int(a["n_states"]), "n_transitions": int(a["tr_off"][-1]), "runs": []}
-    for beam in (200.0, 1e10):
+    for beam in (200.0, 1000.0):      # (unpruned: tools/decode_bench.py -- the start state's whole serial chain every frame, 1.1 s)
         hmm.set_sweep(host.DECODE_FRONTIER, 8 << 30)
         hmm.viterbi(emis_d, 40, 1, fo, beam, 1)
         ctx.profile_enable(True)
