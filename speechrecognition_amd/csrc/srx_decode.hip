@@ -121,7 +121,8 @@ static int wide_suffix_tables(srx_decode_plan *p, const float *tr_logp) {
         double sum = 0.0;
         for (int k = K - 1; k >= 0; k--) {
             const float v = tr_logp[t0 + k];
-            if (!(v <= mx)) mx = v;               // a NaN score ends up in mx: the kernel's test then never passes
+            if (v != v) mx = __builtin_huge_valf();   // a NaN score: +inf from here down, the kernel's test then never passes
+            else if (v > mx) mx = v;
             sum += fabs((double)v);
             if (k % FR_TILE == 0) {
                 lpmax[base + k / FR_TILE] = mx;
