@@ -385,7 +385,7 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
     def nums(fn, tag):
         return np.array([[float(v) for v in ln.split()[1:]] for ln in open(fn).read().split("\n") if ln.startswith(tag)])
 
-    def launch2(args, outs):
+    def launch2(args, outs, env=env):
         shm = "/srx_t_%d_%d" % (os.getpid(), rng.integers(1 << 30))
         ps = []
         for r in range(2):
@@ -415,6 +415,16 @@ def test_headless_driver_mfcc_train_align(oracle, tmp_path):
         assert np.array_equal(np.isnan(g2), np.isnan(ref))
         np.testing.assert_allclose(g2[ok], ref[ok], rtol=1e-7, atol=1e-9)     # the single-process oracle
     np.testing.assert_allclose(nums(outs[0], "mean")[ok], gm[ok], rtol=1e-9, atol=1e-12)   # and the one-rank run of the driver
+    # the driver's default statistics (one pass, ONE exchange per iteration) across two ranks: identical on both, and the
+    # one-rank model of the same path up to the order in which the two shards' sums are added
+    outs = [root + "fused_r0.txt", root + "fused_r1.txt"]
+    launch2(["--mode", "train", "--voxforge", root, "--iters", str(iters), "--model", root + "init.txt"], outs,
+            env={"SRX_SCORE_PATH": "exact", "SRX_EM_PATH": "fused"})
+    assert open(outs[0]).read() == open(outs[1]).read()
+    for tag in ("mean", "var"):
+        one, two = nums(root + "trained_fused.txt", tag), nums(outs[0], tag)
+        assert np.array_equal(np.isnan(one), np.isnan(two))
+        np.testing.assert_allclose(two[ok], one[ok], rtol=1e-9, atol=1e-12)
     outs = [root + "rand_r0.txt", root + "rand_r1.txt"]
     launch2(["--mode", "train", "--voxforge", root, "--iters", "1"], outs)
     assert open(outs[0]).read() == open(outs[1]).read()
