@@ -344,8 +344,7 @@ def decode_leg(ctx, n_words, T):
                        "recognition end condition (best active state)",
            "n_states": int(a["n_states"]), "n_transitions": int(a["tr_off"][-1]), "runs": []}
     for beam in (200.0, 1000.0):      # (unpruned: tools/decode_bench.py -- the start state's whole serial chain every frame, 1.1 s)
-        hmm.set_sweep(host.DECODE_FRONTIER, 8 << 30)
-        hmm.viterbi(emis_d, 40, 1, fo, beam, 1)
+        hmm.viterbi(emis_d, 40, 1, fo, beam, 1)                # (SRX_DECODE_AUTO: the frontier sweep at this size; default workspace limit)
         ctx.profile_enable(True)
         path, final, fstate, status = hmm.viterbi(emis_d, 40, 1, fo, beam, 1)
         ms, cnt = ctx.profile_query("k_viterbi_frontier")
